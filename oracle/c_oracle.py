@@ -1,0 +1,115 @@
+"""ctypes binding for oracle/libgfdm_oracle.so (the plain-C CPU oracle).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/gfdm_oracle.c.  Used by tests/, smoke()
+and bench.py's cpu_baseline leg.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+DECIDE = {"nearest": 0, "qpsk": 1, "bpsk": 2}
+
+
+def build(cflags=None, out=None):
+    """(Re)build the shared object; returns its path."""
+    out = out or os.path.join(_HERE, "libgfdm_oracle.so")
+    cmd = ["gcc"] + (cflags or ["-O3", "-march=x86-64-v3"]) + ["-fPIC", "-std=c11", "-shared", "-o", out,
+                                                              os.path.join(_HERE, "gfdm_oracle.c"), "-lm"]
+    subprocess.check_call(cmd)
+    return out
+
+
+def load(path=None):
+    global _LIB
+    if path is None and _LIB is not None:
+        return _LIB
+    p = path or os.path.join(_HERE, "libgfdm_oracle.so")
+    if not os.path.exists(p):
+        build(out=p)
+    lib = ctypes.CDLL(p)
+    fp, ip, vp, lg = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_long
+    lib.gfdm_oracle_create.restype = vp
+    lib.gfdm_oracle_create.argtypes = [ctypes.c_int] * 3 + [vp, ctypes.c_int]
+    lib.gfdm_oracle_destroy.argtypes = [vp]
+    lib.gfdm_oracle_block_size.argtypes = [vp]
+    lib.gfdm_oracle_filter_taps.argtypes = [vp, vp]
+    lib.gfdm_oracle_ic_filter_taps.argtypes = [vp, vp]
+    lib.gfdm_oracle_modulate.argtypes = [vp, vp, vp, lg]
+    lib.gfdm_oracle_fft_filter_downsample.argtypes = [vp, vp, vp, vp, lg]
+    lib.gfdm_oracle_transform_subcarriers_to_td.argtypes = [vp, vp, vp, lg]
+    lib.gfdm_oracle_cancel_sc_interference.argtypes = [vp, vp, vp, vp, lg]
+    lib.gfdm_oracle_demodulate.argtypes = [vp, vp, vp, vp, lg]
+    lib.gfdm_oracle_advanced_receive.argtypes = [vp, vp, vp, vp, lg, vp, ctypes.c_int, vp, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    del fp, ip
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+class COracle:
+    """One reference-style kernel object: single-threaded, one block per inner call."""
+
+    def __init__(self, M, K, L, taps, lib=None):
+        self.lib = lib or load()
+        self.M, self.K, self.L, self.N = M, K, L, M * K
+        t = _c64(taps)
+        self.h = self.lib.gfdm_oracle_create(M, K, L, t.ctypes.data, t.size)
+        if not self.h:
+            raise ValueError("number of frequency taps MUST be equal to n_timeslots * overlap")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.gfdm_oracle_destroy(self.h)
+            self.h = None
+
+    def filter_taps(self):
+        out = np.empty(self.M * self.L, np.complex64)
+        self.lib.gfdm_oracle_filter_taps(self.h, out.ctypes.data)
+        return out
+
+    def ic_filter_taps(self):
+        out = np.empty(self.M, np.complex64)
+        self.lib.gfdm_oracle_ic_filter_taps(self.h, out.ctypes.data)
+        return out
+
+    def _run(self, fn, *arrays, extra=()):
+        ins = [None if a is None else _c64(a) for a in arrays]
+        first = ins[0]
+        nblocks = first.size // self.N
+        assert first.size == nblocks * self.N
+        out = np.empty_like(first)
+        ptrs = [None if a is None else a.ctypes.data for a in ins]
+        fn(self.h, out.ctypes.data, *ptrs, nblocks, *extra)
+        return out
+
+    def modulate(self, x):
+        return self._run(self.lib.gfdm_oracle_modulate, x)
+
+    def fft_filter_downsample(self, x, f_eq=None):
+        return self._run(self.lib.gfdm_oracle_fft_filter_downsample, x, f_eq)
+
+    def transform_subcarriers_to_td(self, x):
+        return self._run(self.lib.gfdm_oracle_transform_subcarriers_to_td, x)
+
+    def cancel_sc_interference(self, td, fd):
+        return self._run(self.lib.gfdm_oracle_cancel_sc_interference, td, fd)
+
+    def demodulate(self, x, f_eq=None):
+        return self._run(self.lib.gfdm_oracle_demodulate, x, f_eq)
+
+    def advanced_receive(self, x, smap, points, ic_iter, f_eq=None, do_phase_compensation=0, kind="nearest"):
+        smap = np.ascontiguousarray(smap, dtype=np.int32)
+        pts = _c64(points)
+        return self._run(self.lib.gfdm_oracle_advanced_receive, x, f_eq,
+                         extra=(smap.ctypes.data, smap.size, pts.ctypes.data, pts.size, DECIDE[kind], ic_iter,
+                                do_phase_compensation))

@@ -1,0 +1,39 @@
+/* CPU oracle (plain C, float32) for the gr-gfdm sparse-frequency-domain kernels.
+ *
+ * TEST INFRASTRUCTURE ONLY: linked/loaded by tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg -- never by the product path.
+ * See gfdm_oracle.c for the reference lines each function follows.
+ *
+ * All sample buffers are interleaved (re, im) float32, i.e. std::complex<float>.
+ */
+#ifndef GFDM_ORACLE_H
+#define GFDM_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gfdm_oracle gfdm_oracle;
+
+enum { GFDM_ORACLE_DECIDE_NEAREST = 0, GFDM_ORACLE_DECIDE_QPSK = 1, GFDM_ORACLE_DECIDE_BPSK = 2 };
+
+/* returns NULL when ntaps != timeslots*overlap (the reference's invalid_argument) */
+gfdm_oracle* gfdm_oracle_create(int timeslots, int subcarriers, int overlap, const float* taps, int ntaps);
+void gfdm_oracle_destroy(gfdm_oracle* o);
+int gfdm_oracle_block_size(const gfdm_oracle* o);
+void gfdm_oracle_filter_taps(const gfdm_oracle* o, float* out);    /* overlap*timeslots complex */
+void gfdm_oracle_ic_filter_taps(const gfdm_oracle* o, float* out); /* timeslots complex */
+
+void gfdm_oracle_modulate(gfdm_oracle* o, float* out, const float* in, long nblocks);
+void gfdm_oracle_fft_filter_downsample(gfdm_oracle* o, float* out, const float* in, const float* f_eq, long nblocks);
+void gfdm_oracle_transform_subcarriers_to_td(gfdm_oracle* o, float* out, const float* in, long nblocks);
+void gfdm_oracle_cancel_sc_interference(gfdm_oracle* o, float* out, const float* td, const float* fd, long nblocks);
+void gfdm_oracle_demodulate(gfdm_oracle* o, float* out, const float* in, const float* f_eq, long nblocks);
+void gfdm_oracle_advanced_receive(gfdm_oracle* o, float* out, const float* in, const float* f_eq, long nblocks,
+                                  const int* subcarrier_map, int nsubcarrier_map, const float* points, int npoints,
+                                  int decision_kind, int ic_iter, int do_phase_compensation);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,191 @@
+"""CPU oracle (numpy, float64) for the gr-gfdm sparse-frequency-domain kernels.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product path (gr-gfdm_amd/, the C-ABI
+library, the C++ classes, the pybind11 module) may import or call this file;
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and
+only as the checker.
+
+It is a restatement of the reference algorithm, stage by stage, vectorised over
+a leading batch axis.  Each function cites the reference lines it follows
+(paths relative to the gr-gfdm checkout):
+
+  modulator    lib/modulator_kernel_cc.cc:70-141
+  receiver     lib/receiver_kernel_cc.cc:56-63, 99-118, 165-192, 211-225, 274-334
+  IC receiver  lib/advanced_receiver_kernel_cc.cc:56-123
+
+Pinning (see DESIGN.md "Oracle"):
+  * modulate (any overlap) and demodulate (overlap == 2) are checked against
+    golden vectors produced by the reference's own Python model `pygfdm`
+    (tests/golden/make_golden.py, run in the build container), exactly the
+    expectation the reference's C++ tests use (python/qa_python_bindings.py:254-440).
+  * cancel_sc_interference / the IC loop are pinned by the reference tests'
+    known-answer properties (genie IC -> data to 1 place, loop-back IC
+    convergence to 2 places / 1 place: python/qa_python_bindings.py:410-415,
+    python/qa_advanced_receiver_sb_cc.py:119,172).
+  * the receiver at overlap != 2 has NO reference expectation (pygfdm's
+    receiver hard-codes overlap 2, python/pygfdm/gfdm_receiver.py:54,207);
+    it is pinned only through the transpose identity with the (pinned)
+    modulator, tests/test_oracle.py::test_receiver_is_transpose_of_modulator.
+  * the C++ reference itself is unbuildable here (needs FFTW3f, VOLK and
+    GNU Radio headers, none installed) and was NOT built against stand-ins.
+
+All arithmetic is complex128; callers round to complex64 where they compare
+with float32 results.
+"""
+import numpy as np
+
+__all__ = [
+    "normalize_taps", "ic_filter_taps", "modulate", "fft_filter_downsample",
+    "transform_subcarriers_to_td", "cancel_sc_interference", "demodulate",
+    "qpsk_points", "decide", "advanced_receive", "phase_offset",
+]
+
+
+def _c128(x):
+    return np.asarray(x, dtype=np.complex128)
+
+
+def normalize_taps(taps, timeslots):
+    """taps * 1/sqrt(|sum t conj(t)| / M)  -- lib/modulator_kernel_cc.cc:70-85,
+    lib/receiver_kernel_cc.cc:99-113.  The reference computes the factor in
+    double and stores float32 taps."""
+    t = _c128(taps)
+    energy = abs(np.sum(t * np.conj(t)))
+    return t * (1.0 / np.sqrt(energy / timeslots))
+
+
+def ic_filter_taps(ntaps, timeslots, overlap):
+    """ic[m] = t[m] * t[(L-1)M + m]  -- lib/receiver_kernel_cc.cc:56-63."""
+    t = _c128(ntaps)
+    return t[0:timeslots] * t[timeslots * (overlap - 1):timeslots * overlap]
+
+
+def _part_index(K, L):
+    """src/target part positions shared by modulator and receiver:
+    tap part ((i + L/2) % L), spectrum part ((k + i + K - L/2) % K)
+    -- lib/modulator_kernel_cc.cc:118-122, lib/receiver_kernel_cc.cc:175-178."""
+    k = np.arange(K)[:, None]
+    i = np.arange(L)[None, :]
+    tap_part = np.broadcast_to((i + L // 2) % L, (K, L))
+    spec_part = (k + i + K - L // 2) % K
+    return tap_part, spec_part
+
+
+def modulate(symbols, ntaps, M, K, L):
+    """modulator_kernel_cc::generic_work -- lib/modulator_kernel_cc.cc:98-141.
+
+    symbols: (..., K*M) subcarrier-major [k][m]; ntaps: normalised taps (L*M).
+    Returns (..., K*M) time samples.
+    """
+    d = _c128(symbols)
+    batch = d.shape[:-1]
+    D = np.fft.fft(d.reshape(batch + (K, M)), axis=-1)          # :109-110
+    t = _c128(ntaps).reshape(L, M)
+    part_len = min(M * L // 2, M)                                 # :101
+    tap_part, spec_part = _part_index(K, L)
+    Y = np.zeros(batch + (K, M), dtype=np.complex128)             # :104
+    for i in range(L):                                            # spec_part[:, i] is a permutation of k
+        filtered = D * t[tap_part[0, i]]                          # :124-127
+        Y[..., spec_part[:, i], :part_len] += filtered[..., :part_len]      # :129-132
+    x = np.fft.ifft(Y.reshape(batch + (K * M,)), axis=-1)         # :137-140 (ifft = bwd / N)
+    return x
+
+
+def fft_filter_downsample(frame, ntaps, M, K, L, f_eq=None):
+    """receiver_kernel_cc::fft_[equalize_]filter_downsample
+    -- lib/receiver_kernel_cc.cc:301-320 with :165-192."""
+    x = _c128(frame)
+    batch = x.shape[:-1]
+    X = np.fft.fft(x, axis=-1)                                    # :304-305
+    if f_eq is not None:
+        X = X / _c128(f_eq)                                       # :315-316
+    X = X.reshape(batch + (K, M))
+    t = _c128(ntaps).reshape(L, M)
+    tap_part, spec_part = _part_index(K, L)
+    S = np.zeros(batch + (K, M), dtype=np.complex128)             # :168
+    for i in range(L):
+        S += t[tap_part[:, i]] * X[..., spec_part[:, i], :]       # :180-188
+    return S.reshape(batch + (K * M,))
+
+
+def transform_subcarriers_to_td(fd, M, K):
+    """receiver_kernel_cc::transform_subcarriers_to_td -- :211-225 (ifft = bwd / M)."""
+    S = _c128(fd)
+    batch = S.shape[:-1]
+    return np.fft.ifft(S.reshape(batch + (K, M)), axis=-1).reshape(batch + (K * M,))
+
+
+def cancel_sc_interference(td, fd, ictaps, M, K):
+    """receiver_kernel_cc::cancel_sc_interference -- :274-299."""
+    d = _c128(td)
+    batch = d.shape[:-1]
+    d = d.reshape(batch + (K, M))
+    S = _c128(fd).reshape(batch + (K, M))
+    neigh = np.roll(d, 1, axis=-2) + np.roll(d, -1, axis=-2)     # prev_sc + next_sc :279-284
+    out = S - _c128(ictaps) * np.fft.fft(neigh, axis=-1)          # :285-296
+    return out.reshape(batch + (K * M,))
+
+
+def demodulate(frame, ntaps, M, K, L, f_eq=None):
+    """receiver_kernel_cc::generic_work / generic_work_equalize -- :322-334."""
+    return transform_subcarriers_to_td(fft_filter_downsample(frame, ntaps, M, K, L, f_eq), M, K)
+
+
+def qpsk_points():
+    """gr::digital::constellation_qpsk (GNU Radio gr-digital, not in the
+    reference tree): points in index order --, +-, -+, ++ over sqrt(2);
+    decision_maker = 2*(imag > 0) + (real > 0).  Parity unpinned beyond the
+    reference's 1-2 decimal-place IC tests."""
+    s = np.sqrt(0.5)
+    return np.array([-s - 1j * s, s - 1j * s, -s + 1j * s, s + 1j * s], dtype=np.complex128)
+
+
+def decide(x, points, kind="nearest"):
+    """Hard decision.  kind 'qpsk' follows constellation_qpsk::decision_maker
+    (sign test, zero maps to the negative point); 'nearest' is the generic
+    minimum-Euclidean-distance rule, first minimum wins."""
+    x = _c128(x)
+    p = _c128(points)
+    if kind == "qpsk":
+        idx = 2 * (x.imag > 0).astype(np.int64) + (x.real > 0).astype(np.int64)
+    elif kind == "bpsk":
+        idx = (x.real > 0).astype(np.int64)
+    else:
+        dist = np.abs(x[..., None] - p) ** 2
+        idx = np.argmin(dist, axis=-1)
+    return p[idx]
+
+
+def phase_offset(detected, demod, smap, M, K):
+    """advanced_receiver_kernel_cc::calculate_phase_offset -- .cc:78-91:
+    mean over active (k, m) of arg(detected) - arg(demod), no unwrapping."""
+    batch = detected.shape[:-1]
+    a = np.angle(detected.reshape(batch + (K, M))[..., smap, :])
+    b = np.angle(demod.reshape(batch + (K, M))[..., smap, :])
+    return (a - b).sum(axis=(-1, -2)) / (len(smap) * M)
+
+
+def advanced_receive(frame, ntaps, M, K, L, smap, points, ic_iter, f_eq=None,
+                     do_phase_compensation=0, kind="nearest", return_stages=False):
+    """advanced_receiver_kernel_cc::generic_work[_equalize] -- .cc:93-107 with
+    perform_ic_iterations :56-76 and map_symbols_to_constellation_points :109-123."""
+    smap = np.asarray(smap, dtype=np.int64)
+    ic = ic_filter_taps(ntaps, M, L)
+    S = fft_filter_downsample(frame, ntaps, M, K, L, f_eq)
+    out = transform_subcarriers_to_td(S, M, K)
+    batch = out.shape[:-1]
+    stages = {"S": S.copy(), "d0": out.copy(), "iters": []}
+    for j in range(ic_iter):
+        dec = np.zeros(batch + (K, M), dtype=np.complex128)                  # memset :112
+        dec[..., smap, :] = decide(out.reshape(batch + (K, M))[..., smap, :], points, kind)
+        dec = dec.reshape(batch + (K * M,))
+        if do_phase_compensation > 0 and j == 0:                            # :59-71
+            phi = phase_offset(dec, out, smap, M, K)
+            S = S * np.exp(1j * np.asarray(phi))[..., None]
+        fd = cancel_sc_interference(dec, S, ic, M, K)                        # :72-73
+        out = transform_subcarriers_to_td(fd, M, K)                          # :74
+        stages["iters"].append(out.copy())
+    if return_stages:
+        stages["dec_margin"] = None
+        return out, stages
+    return out
