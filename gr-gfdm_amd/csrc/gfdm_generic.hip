@@ -1,0 +1,363 @@
+// Generic HIP kernel family: any (timeslots M, subcarriers K, overlap L) whose block fits LDS.
+//
+// One 256-thread workgroup per GFDM block.  The K x M block lives in LDS tiles for the whole
+// computation, so HBM sees exactly one read of the inputs and one write of the output.
+// The N = K*M point transform is factored along GFDM's own structure (n = K p + q, f = M j + m):
+//     X[M j + m] = sum_q W_K^{q j} * W_N^{q m} * ( sum_p x[K p + q] W_M^{p m} )
+// i.e. M-point DFTs over the timeslot axis, a twiddle, K-point FFTs over the subcarrier axis.
+// This family uses table-driven direct DFTs for the M axis and a radix-2 Stockham FFT (or a
+// direct DFT when K is not a power of two) for the K axis: it is the shape-agnostic path, the
+// tuned register/LDS family for the benchmark shapes is gfdm_fast.hip.
+//
+// Algorithm restated from (gr-gfdm checkout):
+//   modulator  lib/modulator_kernel_cc.cc:98-141
+//   receiver   lib/receiver_kernel_cc.cc:165-192, 211-225, 274-334
+//   IC loop    lib/advanced_receiver_kernel_cc.cc:56-123
+#include "gfdm_plan.h"
+
+namespace gfdm {
+namespace {
+
+constexpr int GT = 256;           // threads per workgroup
+constexpr int RED_BYTES = 1024;   // reduction scratch carved from the dynamic LDS region
+
+__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf cmulj(cf a, cf b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cfma(cf a, cf b, cf c) { return make_float2(c.x + a.x * b.x - a.y * b.y, c.y + a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf cfmaj(cf a, cf b, cf c) { return make_float2(c.x + a.x * b.x + a.y * b.y, c.y + a.y * b.x - a.x * b.y); }
+__device__ __forceinline__ cf cdiv(cf a, cf b)
+{
+    const float d = b.x * b.x + b.y * b.y;
+    return make_float2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+
+// dst[r*M + m] = scale * sum_p src[r*rs + p*ps] * W_M^{+-(p m)}      (dst may be LDS or global)
+template <bool INV>
+__device__ void row_dft(cf* dst, const cf* src, int rows, int M, int rs, int ps, const cf* __restrict__ wM, float scale)
+{
+    for (int idx = threadIdx.x; idx < rows * M; idx += GT) {
+        const int r = idx / M, m = idx - r * M;
+        cf acc = make_float2(0.f, 0.f);
+        int e = 0;
+        for (int p = 0; p < M; ++p) {
+            const cf w = wM[e];
+            const cf v = src[r * rs + p * ps];
+            acc = INV ? cfmaj(v, w, acc) : cfma(v, w, acc);
+            e += m;
+            if (e >= M) e -= M;
+        }
+        dst[idx] = make_float2(acc.x * scale, acc.y * scale);
+    }
+}
+
+// K-point transform along the subcarrier axis of a [K][M] LDS tile, all M columns at once.
+// Data in `a`, scratch `b`; returns the tile that holds the result.  Caller syncs before.
+template <bool INV>
+__device__ cf* col_fft(cf* a, cf* b, const DevicePlan& p)
+{
+    const int M = p.M, K = p.K;
+    const cf* __restrict__ wK = p.wK;
+    cf* x = a;
+    cf* y = b;
+    if (p.log2K >= 0) {
+        const int nbf = (K >> 1) * M;
+        for (int s = 0; s < p.log2K; ++s) {
+            const int str = 1 << s, half = K >> (s + 1);
+            for (int idx = threadIdx.x; idx < nbf; idx += GT) {
+                const int bf = idx / M, m = idx - bf * M;
+                const int j = bf & (str - 1), qq = bf >> s;
+                const cf u = x[(j + str * qq) * M + m];
+                const cf v = x[(j + str * (qq + half)) * M + m];
+                const cf w = wK[qq << s];                         // W_len^{qq}, len = K >> s
+                const cf d = csub(u, v);
+                y[(j + str * (2 * qq)) * M + m] = cadd(u, v);
+                y[(j + str * (2 * qq + 1)) * M + m] = INV ? cmulj(d, w) : cmul(d, w);
+            }
+            __syncthreads();
+            cf* t = x; x = y; y = t;
+        }
+        return x;
+    }
+    for (int idx = threadIdx.x; idx < K * M; idx += GT) {
+        const int j = idx / M, m = idx - j * M;
+        cf acc = make_float2(0.f, 0.f);
+        int e = 0;
+        for (int q = 0; q < K; ++q) {
+            const cf w = wK[e];
+            acc = INV ? cfmaj(x[q * M + m], w, acc) : cfma(x[q * M + m], w, acc);
+            e += j;
+            if (e >= K) e -= K;
+        }
+        y[idx] = acc;
+    }
+    __syncthreads();
+    return y;
+}
+
+__device__ __forceinline__ cf decide(cf x, const IcParams& ic)
+{
+    int idx;
+    if (ic.decision == 1) {
+        idx = 2 * (x.y > 0.f) + (x.x > 0.f);
+    } else if (ic.decision == 2) {
+        idx = (x.x > 0.f);
+    } else {
+        idx = 0;
+        float best = INFINITY;
+        for (int i = 0; i < ic.npoints; ++i) {
+            const cf pt = ic.points[i];
+            const float dr = x.x - pt.x, di = x.y - pt.y, d = dr * dr + di * di;
+            if (d < best) { best = d; idx = i; }
+        }
+    }
+    return ic.points[idx];
+}
+
+// out[k][m] = fd[k][m] - ic[m] * sum_p (td[k-1][p] + td[k+1][p]) W_M^{p m}     (receiver_kernel_cc.cc:274-299)
+__device__ void cancel_rows(cf* dst, const cf* td, const cf* fd, const DevicePlan& p)
+{
+    const int M = p.M, K = p.K;
+    for (int idx = threadIdx.x; idx < p.N; idx += GT) {
+        const int k = idx / M, m = idx - k * M;
+        const cf* prev = td + ((k - 1 + K) % K) * M;
+        const cf* next = td + ((k + 1) % K) * M;
+        cf acc = make_float2(0.f, 0.f);
+        int e = 0;
+        for (int q = 0; q < M; ++q) {
+            acc = cfma(cadd(prev[q], next[q]), p.wM[e], acc);
+            e += m;
+            if (e >= M) e -= M;
+        }
+        dst[idx] = csub(fd[idx], cmul(p.ictaps[m], acc));
+    }
+}
+
+__global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan p, cf* __restrict__ out, const cf* __restrict__ in)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* t0 = reinterpret_cast<cf*>(smem);
+    cf* t1 = t0 + p.N;
+    const int M = p.M, K = p.K, L = p.L, N = p.N;
+    const cf* x = in + (int64_t)blockIdx.x * N;
+    cf* o = out + (int64_t)blockIdx.x * N;
+
+    for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
+    __syncthreads();
+    row_dft<false>(t0, t1, K, M, M, 1, p.wM, 1.f);                 // D_k = FFT_M(d_k)                 :109-110
+    __syncthreads();
+    // gather form of the filter + overlap-add scatter (:116-132):
+    //   Y[j][m] = sum_i D[(j - i + L/2) mod K][m] * taps[((i + L/2) % L) M + m],  m < part_len
+    for (int idx = threadIdx.x; idx < N; idx += GT) {
+        const int j = idx / M, m = idx - j * M;
+        cf acc = make_float2(0.f, 0.f);
+        if (m < p.part_len) {
+            for (int i = 0; i < L; ++i) {
+                const int k = ((j - i + L / 2) % K + K) % K;
+                acc = cfma(t0[k * M + m], p.taps[((i + L / 2) % L) * M + m], acc);
+            }
+        }
+        t1[idx] = acc;
+    }
+    __syncthreads();
+    cf* z = col_fft<true>(t1, t0, p);                              // K-point inverse over j
+    cf* u = (z == t1) ? t0 : t1;
+    for (int idx = threadIdx.x; idx < N; idx += GT) {              // twiddle conj(W_N^{q m})
+        const int q = idx / M, m = idx - q * M;
+        u[idx] = cmulj(z[idx], p.wN[q * m]);
+    }
+    __syncthreads();
+    // x[K p + q] = (1/N) sum_m u[q][m] conj(W_M^{p m});  q fastest so the global store is coalesced   :137-140
+    const float scale = 1.f / (float)N;
+    for (int idx = threadIdx.x; idx < N; idx += GT) {
+        const int pp = idx / K, q = idx - pp * K;
+        cf acc = make_float2(0.f, 0.f);
+        int e = 0;
+        for (int m = 0; m < M; ++m) {
+            acc = cfmaj(u[q * M + m], p.wM[e], acc);
+            e += pp;
+            if (e >= M) e -= M;
+        }
+        o[idx] = make_float2(acc.x * scale, acc.y * scale);
+    }
+}
+
+__global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams ic, int mode, int s_in_global, cf* __restrict__ out,
+                                                        const cf* __restrict__ in, const cf* __restrict__ f_eq)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    cf* t0 = reinterpret_cast<cf*>(smem + RED_BYTES);
+    cf* t1 = t0 + p.N;
+    cf* t2 = t1 + p.N;                                             // only valid when 3 tiles were requested
+    const int M = p.M, K = p.K, L = p.L, N = p.N;
+    const cf* x = in + (int64_t)blockIdx.x * N;
+    cf* o = out + (int64_t)blockIdx.x * N;
+    const cf* eq = f_eq ? f_eq + (int64_t)blockIdx.x * N : nullptr;
+
+    for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
+    __syncthreads();
+    // A[q][m] = W_N^{q m} * sum_p x[K p + q] W_M^{p m}
+    for (int idx = threadIdx.x; idx < N; idx += GT) {
+        const int q = idx / M, m = idx - q * M;
+        cf acc = make_float2(0.f, 0.f);
+        int e = 0;
+        for (int pp = 0; pp < M; ++pp) {
+            acc = cfma(t1[K * pp + q], p.wM[e], acc);
+            e += m;
+            if (e >= M) e -= M;
+        }
+        t0[idx] = cmul(acc, p.wN[q * m]);
+    }
+    __syncthreads();
+    cf* X = col_fft<false>(t0, t1, p);                             // X[j][m] = FFT_N(x)[M j + m]       :304-305
+    cf* U = (X == t0) ? t1 : t0;
+    if (eq) {                                                      // one-tap equaliser                 :315-316
+        for (int idx = threadIdx.x; idx < N; idx += GT) X[idx] = cdiv(X[idx], eq[idx]);
+        __syncthreads();
+    }
+    // S[k][m] = sum_i taps[((i + L/2) % L) M + m] * X[((k + i + K - L/2) % K) M + m]                    :165-192
+    cf* Sdst = (mode == RX_FD) ? o : U;
+    for (int idx = threadIdx.x; idx < N; idx += GT) {
+        const int k = idx / M, m = idx - k * M;
+        cf acc = make_float2(0.f, 0.f);
+        for (int i = 0; i < L; ++i)
+            acc = cfma(p.taps[((i + L / 2) % L) * M + m], X[((k + i + K - L / 2) % K) * M + m], acc);
+        Sdst[idx] = acc;
+    }
+    if (mode == RX_FD) return;
+    __syncthreads();
+    const float invM = 1.f / (float)M;
+    if (mode == RX_DEMOD || ic.ic_iter <= 0) {
+        row_dft<true>(o, U, K, M, M, 1, p.wM, invM);              // d = IFFT_M(S_k) / M                :211-225
+        return;
+    }
+    cf* D = X;
+    row_dft<true>(D, U, K, M, M, 1, p.wM, invM);
+    cf* S = U;
+    cf* V = t2;
+    if (s_in_global) {                                            // third tile does not fit: park S in the output block
+        for (int idx = threadIdx.x; idx < N; idx += GT) o[idx] = U[idx];
+        S = o;
+        V = U;
+    }
+    __syncthreads();
+    for (int j = 0; j < ic.ic_iter; ++j) {                        // perform_ic_iterations            adv:56-76
+        if (ic.do_phase_compensation > 0 && j == 0) {              // calculate_phase_offset           adv:78-91
+            float acc = 0.f;
+            for (int idx = threadIdx.x; idx < ic.n_active * M; idx += GT) {
+                const int a = idx / M, m = idx - a * M;
+                const cf v = D[ic.smap[a] * M + m];
+                const cf d = decide(v, ic);
+                acc += atan2f(d.y, d.x) - atan2f(v.y, v.x);
+            }
+            red[threadIdx.x] = acc;
+            __syncthreads();
+            for (int s = GT / 2; s > 0; s >>= 1) {
+                if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+                __syncthreads();
+            }
+            const float phi = red[0] / (float)(ic.n_active * M);
+            float sn, cs;
+            sincosf(phi, &sn, &cs);
+            const cf rot = make_float2(cs, sn);
+            for (int idx = threadIdx.x; idx < N; idx += GT) S[idx] = cmul(S[idx], rot);   // in place, persists  adv:63-70
+            __syncthreads();
+        }
+        for (int idx = threadIdx.x; idx < N; idx += GT)           // map_symbols_to_constellation_points  adv:109-123
+            D[idx] = ic.active[idx / M] ? decide(D[idx], ic) : make_float2(0.f, 0.f);
+        __syncthreads();
+        cancel_rows(V, D, S, p);
+        __syncthreads();
+        if (j == ic.ic_iter - 1) {
+            row_dft<true>(o, V, K, M, M, 1, p.wM, invM);
+        } else {
+            row_dft<true>(D, V, K, M, M, 1, p.wM, invM);
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(GT) void k_generic_to_td(DevicePlan p, cf* __restrict__ out, const cf* __restrict__ in)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* t0 = reinterpret_cast<cf*>(smem);
+    const cf* x = in + (int64_t)blockIdx.x * p.N;
+    for (int idx = threadIdx.x; idx < p.N; idx += GT) t0[idx] = x[idx];
+    __syncthreads();
+    row_dft<true>(out + (int64_t)blockIdx.x * p.N, t0, p.K, p.M, p.M, 1, p.wM, 1.f / (float)p.M);
+}
+
+__global__ __launch_bounds__(GT) void k_generic_cancel(DevicePlan p, cf* __restrict__ out, const cf* __restrict__ td,
+                                                       const cf* __restrict__ fd)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* t0 = reinterpret_cast<cf*>(smem);
+    const cf* x = td + (int64_t)blockIdx.x * p.N;
+    for (int idx = threadIdx.x; idx < p.N; idx += GT) t0[idx] = x[idx];
+    __syncthreads();
+    cancel_rows(out + (int64_t)blockIdx.x * p.N, t0, fd + (int64_t)blockIdx.x * p.N, p);
+}
+
+constexpr size_t LDS_MAX = 160 * 1024;
+
+template <typename KernelT>
+hipError_t allow_lds(KernelT kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+size_t generic_lds_bytes(int N, int ntiles) { return (size_t)ntiles * (size_t)N * sizeof(cf) + RED_BYTES; }
+
+bool generic_supports(int N, bool) { return generic_lds_bytes(N, 2) <= LDS_MAX; }
+
+hipError_t launch_generic_modulate(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return hipSuccess;
+    const size_t lds = generic_lds_bytes(p.N, 2);
+    hipError_t e = allow_lds(k_generic_modulate, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_generic_modulate, dim3((unsigned)nblocks), dim3(GT), lds, s, p, out, in);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq,
+                                  int64_t nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return hipSuccess;
+    int ntiles = 2, s_in_global = 0;
+    if (mode == RX_IC && ic.ic_iter > 0) {
+        if (generic_lds_bytes(p.N, 3) <= LDS_MAX) ntiles = 3; else s_in_global = 1;
+    }
+    const size_t lds = generic_lds_bytes(p.N, ntiles);
+    hipError_t e = allow_lds(k_generic_receive, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_generic_receive, dim3((unsigned)nblocks), dim3(GT), lds, s, p, ic, mode, s_in_global, out, in, f_eq);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return hipSuccess;
+    const size_t lds = generic_lds_bytes(p.N, 1);
+    hipError_t e = allow_lds(k_generic_to_td, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_generic_to_td, dim3((unsigned)nblocks), dim3(GT), lds, s, p, out, in);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, const cf* fd, int64_t nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return hipSuccess;
+    const size_t lds = generic_lds_bytes(p.N, 1);
+    hipError_t e = allow_lds(k_generic_cancel, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_generic_cancel, dim3((unsigned)nblocks), dim3(GT), lds, s, p, out, td, fd);
+    return hipGetLastError();
+}
+
+}  // namespace gfdm

@@ -1,0 +1,53 @@
+// Internal: device-side plan shared by the HIP kernel families and the C-ABI shim.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gfdm {
+
+typedef float2 cf;
+
+// Everything a kernel needs to know about one (timeslots, subcarriers, overlap, taps) configuration.
+// Tables live in device memory, are built once per handle (double precision on the host, rounded to f32).
+struct DevicePlan {
+    int M;          // timeslots
+    int K;          // subcarriers
+    int L;          // overlap
+    int N;          // M * K
+    int log2K;      // >= 0 when K is a power of two, else -1
+    int part_len;   // min(M*L/2, M): bins of each tap part the modulator accumulates (modulator_kernel_cc.cc:101)
+    const cf* taps;     // [L*M] normalised filter taps
+    const cf* ictaps;   // [M]   ic[m] = t[m] * t[(L-1)M + m]
+    const cf* wM;       // [M]   exp(-2 pi j p / M)
+    const cf* wK;       // [K]   exp(-2 pi j q / K)
+    const cf* wN;       // [N]   exp(-2 pi j r / N)
+};
+
+// Interference-cancellation settings of advanced_receiver_kernel_cc.
+struct IcParams {
+    int ic_iter;
+    int do_phase_compensation;
+    int decision;              // gfdm_hip_decision (never AUTO on the device)
+    int npoints;
+    const cf* points;          // [npoints]
+    const unsigned char* active;   // [K] 1 when the subcarrier is in subcarrier_map
+    int n_active;              // subcarrier_map.size() (duplicates counted, as the reference does)
+    const int* smap;           // [n_active] the subcarrier_map itself (order matters for the phase sum)
+};
+
+enum RxMode {
+    RX_FD = 0,        // fft_[equalize_]filter_downsample: out = S
+    RX_DEMOD = 1,     // generic_work[_equalize]:         out = IDFT_M(S)/M
+    RX_IC = 2         // advanced receiver:               out after ic_iter cancellation rounds
+};
+
+// ---- generic family (any M, K, L; one workgroup per block, everything staged in LDS) ----
+size_t generic_lds_bytes(int N, int ntiles);
+hipError_t launch_generic_modulate(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq,
+                                  int64_t nblocks, hipStream_t s);
+hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, const cf* fd, int64_t nblocks, hipStream_t s);
+bool generic_supports(int N, bool ic);
+
+}  // namespace gfdm

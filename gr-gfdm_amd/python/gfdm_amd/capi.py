@@ -1,0 +1,326 @@
+"""ctypes binding of the C-ABI in include/gfdm_hip.h (gr-gfdm_amd/lib/libgfdm_hip.so).
+
+Host-side mirror of the reference's kernel-class surface for Python callers that
+work on whole batches and on device-resident torch tensors (bench.py, the
+multi-GPU sharding helper).  The pybind11 module `gfdm_python` is the drop-in for
+the reference's own binding; this module adds nothing numerically, it only
+forwards pointers.  There is no CPU fallback: a missing library or GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.normpath(os.path.join(_PKG, "..", "..", "lib"))
+LIB_PATH = os.path.join(LIB_DIR, "libgfdm_hip.so")
+
+OK, EINVAL_TAPS, EINVAL_OVERLAP, EINVAL, ENODEV, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
+DECIDE = {"auto": -1, "nearest": 0, "qpsk": 1, "bpsk": 2}
+
+_lib = None
+
+
+class GfdmHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("gfdm_hip error %d: %s" % (status, message))
+        self.status = status
+
+
+def lib():
+    """Load libgfdm_hip.so (built by `make -C gr-gfdm_amd` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `make -C gr-gfdm_amd` (no CPU fallback exists)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_char_p
+    sig = {
+        "gfdm_hip_strerror": (cp, [i32]),
+        "gfdm_hip_last_error": (cp, []),
+        "gfdm_hip_device_count": (i32, []),
+        "gfdm_hip_version": (cp, []),
+        "gfdm_hip_modulator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
+        "gfdm_hip_modulator_destroy": (i32, [vp]),
+        "gfdm_hip_modulator_block_size": (i32, [vp]),
+        "gfdm_hip_modulator_filter_taps": (i32, [vp, vp]),
+        "gfdm_hip_modulator_kernel_name": (cp, [vp]),
+        "gfdm_hip_modulator_work_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_modulator_work_device": (i32, [vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
+        "gfdm_hip_receiver_destroy": (i32, [vp]),
+        "gfdm_hip_receiver_block_size": (i32, [vp]),
+        "gfdm_hip_receiver_timeslots": (i32, [vp]),
+        "gfdm_hip_receiver_subcarriers": (i32, [vp]),
+        "gfdm_hip_receiver_overlap": (i32, [vp]),
+        "gfdm_hip_receiver_filter_taps": (i32, [vp, vp]),
+        "gfdm_hip_receiver_ic_filter_taps": (i32, [vp, vp]),
+        "gfdm_hip_receiver_kernel_name": (cp, [vp]),
+        "gfdm_hip_receiver_demodulate_host": (i32, [vp, vp, vp, vp, i64]),
+        "gfdm_hip_receiver_demodulate_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_fft_filter_downsample_host": (i32, [vp, vp, vp, vp, i64]),
+        "gfdm_hip_receiver_fft_filter_downsample_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_transform_subcarriers_to_td_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_receiver_transform_subcarriers_to_td_device": (i32, [vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_cancel_sc_interference_host": (i32, [vp, vp, vp, vp, i64]),
+        "gfdm_hip_receiver_cancel_sc_interference_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_advanced_receiver_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, vp, i32, i32, vp, i32, i32, i32, i32]),
+        "gfdm_hip_advanced_receiver_destroy": (i32, [vp]),
+        "gfdm_hip_advanced_receiver_block_size": (i32, [vp]),
+        "gfdm_hip_advanced_receiver_set_ic": (i32, [vp, i32]),
+        "gfdm_hip_advanced_receiver_get_ic": (i32, [vp]),
+        "gfdm_hip_advanced_receiver_set_phase_compensation": (i32, [vp, i32]),
+        "gfdm_hip_advanced_receiver_get_phase_compensation": (i32, [vp]),
+        "gfdm_hip_advanced_receiver_kernel_name": (cp, [vp]),
+        "gfdm_hip_advanced_receiver_work_host": (i32, [vp, vp, vp, vp, i64]),
+        "gfdm_hip_advanced_receiver_work_device": (i32, [vp, vp, vp, vp, i64, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here == the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    L._gfdm_symbols = sorted(sig)
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    return list(lib()._gfdm_symbols)
+
+
+def _check(status):
+    if status == OK:
+        return
+    L = lib()
+    msg = (L.gfdm_hip_last_error() or b"").decode() or L.gfdm_hip_strerror(status).decode()
+    if status in (EINVAL_TAPS, EINVAL_OVERLAP):
+        raise ValueError(msg)            # std::invalid_argument in the reference (pybind11 maps it to ValueError)
+    raise GfdmHipError(status, msg)
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def _is_tensor(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def _dev_ptr(t, n_elems, what):
+    import torch
+    if not t.is_cuda or t.dtype != torch.complex64 or not t.is_contiguous():
+        raise TypeError("%s must be a contiguous complex64 CUDA/HIP tensor" % what)
+    if t.numel() != n_elems:
+        raise RuntimeError("%s has %d elements, expected %d" % (what, t.numel(), n_elems))
+    return t.data_ptr()
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    if hasattr(stream, "cuda_stream"):
+        return stream.cuda_stream
+    return int(stream)
+
+
+class _Kernel:
+    """Shared plumbing: host (numpy) and device (torch) batched calls."""
+    _destroy = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and _lib is not None and self._destroy:
+            getattr(_lib, self._destroy)(h)
+            self._h = None
+
+    def _nblocks(self, size, what="Input"):
+        n = self.block_size()
+        if size % n:
+            raise RuntimeError("%s vector size(%d) MUST be a multiple of block_size(%d)!" % (what, size, n))
+        return size // n
+
+    def _host(self, fn, x, extra=(), extra_ok_none=False):
+        x = _c64(x)
+        nb = self._nblocks(x.size)
+        ptrs = []
+        keep = []
+        for e in extra:
+            if e is None:
+                if not extra_ok_none:
+                    raise RuntimeError("missing input vector")
+                ptrs.append(None)
+            else:
+                e = _c64(e)
+                if e.size != x.size:
+                    raise RuntimeError("Channel vector size(%d) MUST be equal to input size(%d)!" % (e.size, x.size))
+                keep.append(e)
+                ptrs.append(e.ctypes.data)
+        out = np.empty(x.shape, np.complex64)
+        _check(fn(self._h, out.ctypes.data, x.ctypes.data, *ptrs, nb))
+        return out
+
+    def _device(self, fn, out, x, extra=(), stream=None):
+        n = x.numel()
+        nb = self._nblocks(n)
+        ptrs = [None if e is None else _dev_ptr(e, n, "extra input") for e in extra]
+        _check(fn(self._h, _dev_ptr(out, n, "out"), _dev_ptr(x, n, "in"), *ptrs, nb, _stream_ptr(stream)))
+        return out
+
+
+def _taps_arg(taps):
+    t = _c64(np.asarray(taps).ravel())
+    return t, t.ctypes.data, t.size
+
+
+class Modulator(_Kernel):
+    """gr::gfdm::modulator_kernel_cc (include/gfdm/modulator_kernel_cc.h:41-51) on the GPU."""
+    _destroy = "gfdm_hip_modulator_destroy"
+
+    def __init__(self, timeslots, subcarriers, overlap, taps, device=0):
+        L = lib()
+        t, tp, tn = _taps_arg(taps)
+        h = ctypes.c_void_p()
+        _check(L.gfdm_hip_modulator_create(ctypes.byref(h), timeslots, subcarriers, overlap, tp, tn, device))
+        self._h = h
+        self._n = timeslots * subcarriers
+        self._ntaps = tn
+
+    def block_size(self):
+        return self._n
+
+    def kernel_name(self):
+        return lib().gfdm_hip_modulator_kernel_name(self._h).decode()
+
+    def filter_taps(self):
+        out = np.empty(self._ntaps, np.complex64)
+        _check(lib().gfdm_hip_modulator_filter_taps(self._h, out.ctypes.data))
+        return out
+
+    def modulate(self, x, out=None, stream=None):
+        """numpy in -> numpy out (any whole number of blocks); torch CUDA tensor in -> `out` tensor, async on `stream`."""
+        if _is_tensor(x):
+            import torch
+            out = torch.empty_like(x) if out is None else out
+            return self._device(lib().gfdm_hip_modulator_work_device, out, x, stream=stream)
+        return self._host(lib().gfdm_hip_modulator_work_host, x)
+
+
+class Demodulator(_Kernel):
+    """gr::gfdm::receiver_kernel_cc (include/gfdm/receiver_kernel_cc.h:52-89) on the GPU."""
+    _destroy = "gfdm_hip_receiver_destroy"
+
+    def __init__(self, timeslots, subcarriers, overlap, taps, device=0):
+        L = lib()
+        t, tp, tn = _taps_arg(taps)
+        h = ctypes.c_void_p()
+        _check(L.gfdm_hip_receiver_create(ctypes.byref(h), timeslots, subcarriers, overlap, tp, tn, device))
+        self._h = h
+        self._M, self._K, self._L = timeslots, subcarriers, overlap
+
+    def timeslots(self):
+        return lib().gfdm_hip_receiver_timeslots(self._h)
+
+    def subcarriers(self):
+        return lib().gfdm_hip_receiver_subcarriers(self._h)
+
+    def overlap(self):
+        return lib().gfdm_hip_receiver_overlap(self._h)
+
+    def block_size(self):
+        return self._M * self._K
+
+    def kernel_name(self):
+        return lib().gfdm_hip_receiver_kernel_name(self._h).decode()
+
+    def filter_taps(self):
+        out = np.empty(self._M * self._L, np.complex64)
+        _check(lib().gfdm_hip_receiver_filter_taps(self._h, out.ctypes.data))
+        return out
+
+    def ic_filter_taps(self):
+        out = np.empty(self._M, np.complex64)
+        _check(lib().gfdm_hip_receiver_ic_filter_taps(self._h, out.ctypes.data))
+        return out
+
+    def _call(self, name, x, extra, out, stream, extra_ok_none=False):
+        L = lib()
+        if _is_tensor(x):
+            import torch
+            out = torch.empty_like(x) if out is None else out
+            return self._device(getattr(L, name + "_device"), out, x, extra, stream)
+        return self._host(getattr(L, name + "_host"), x, extra, extra_ok_none)
+
+    def demodulate(self, x, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_demodulate", x, (None,), out, stream, True)
+
+    def demodulate_equalize(self, x, f_eq, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_demodulate", x, (f_eq,), out, stream)
+
+    def fft_filter_downsample(self, x, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_fft_filter_downsample", x, (None,), out, stream, True)
+
+    def fft_equalize_filter_downsample(self, x, f_eq, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_fft_filter_downsample", x, (f_eq,), out, stream)
+
+    def transform_subcarriers_to_td(self, x, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_transform_subcarriers_to_td", x, (), out, stream)
+
+    def cancel_sc_interference(self, td, fd, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_cancel_sc_interference", td, (fd,), out, stream)
+
+
+class AdvancedReceiver(_Kernel):
+    """gr::gfdm::advanced_receiver_kernel_cc (include/gfdm/advanced_receiver_kernel_cc.h:37-78) on the GPU.
+
+    The reference takes a gr::digital::constellation_sptr; here the constellation is its points() array plus a
+    decision rule ('auto' picks the QPSK/BPSK sign tests when the points are those constellations)."""
+    _destroy = "gfdm_hip_advanced_receiver_destroy"
+
+    def __init__(self, timeslots, subcarriers, overlap, taps, subcarrier_map, ic_iter, constellation_points,
+                 do_phase_compensation=0, decision="auto", device=0):
+        L = lib()
+        t, tp, tn = _taps_arg(taps)
+        smap = np.ascontiguousarray(subcarrier_map, dtype=np.int32)
+        pts = _c64(np.asarray(constellation_points).ravel())
+        h = ctypes.c_void_p()
+        _check(L.gfdm_hip_advanced_receiver_create(ctypes.byref(h), timeslots, subcarriers, overlap, tp, tn,
+                                                   smap.ctypes.data, smap.size, ic_iter, pts.ctypes.data, pts.size,
+                                                   DECIDE[decision], do_phase_compensation, device))
+        self._h = h
+        self._n = timeslots * subcarriers
+
+    def block_size(self):
+        return self._n
+
+    def kernel_name(self):
+        return lib().gfdm_hip_advanced_receiver_kernel_name(self._h).decode()
+
+    def set_ic(self, ic_iter):
+        _check(lib().gfdm_hip_advanced_receiver_set_ic(self._h, ic_iter))
+
+    def get_ic(self):
+        return lib().gfdm_hip_advanced_receiver_get_ic(self._h)
+
+    def set_phase_compensation(self, enable):
+        _check(lib().gfdm_hip_advanced_receiver_set_phase_compensation(self._h, enable))
+
+    def get_phase_compensation(self):
+        return lib().gfdm_hip_advanced_receiver_get_phase_compensation(self._h)
+
+    def _call(self, x, f_eq, out, stream):
+        L = lib()
+        if _is_tensor(x):
+            import torch
+            out = torch.empty_like(x) if out is None else out
+            return self._device(L.gfdm_hip_advanced_receiver_work_device, out, x, (f_eq,), stream)
+        return self._host(L.gfdm_hip_advanced_receiver_work_host, x, (f_eq,), True)
+
+    def demodulate(self, x, out=None, stream=None):
+        """generic_work: IC receiver without equaliser."""
+        return self._call(x, None, out, stream)
+
+    def demodulate_equalize(self, x, f_eq, out=None, stream=None):
+        """generic_work_equalize: one f_eq vector per block."""
+        return self._call(x, f_eq, out, stream)

@@ -1,0 +1,131 @@
+/* gfdm_hip.h -- C-ABI of the MI355X (gfx950) GFDM modulator / receiver / IC-receiver kernels.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Each entry point names the gr-gfdm interface it replaces (paths relative to
+ * the gr-gfdm checkout).  The GR-free C++ classes of gr-gfdm_amd/cpp/ and the
+ * pybind11 module `gfdm_python` are thin wrappers over these functions; see
+ * INTEGRATION.md for the reference-side binding.
+ *
+ * Conventions
+ *   - samples are interleaved float32 (re, im) == std::complex<float> == gr_complex
+ *     (include/gfdm/gfdm_kernel_utils.h:40).  One GFDM block = timeslots*subcarriers
+ *     samples; batched calls take `nblocks` blocks back to back (block stride = block_size),
+ *     exactly the stream layout the GNU Radio wrappers feed one block at a time
+ *     (lib/simple_receiver_cc_impl.cc:70-74, lib/advanced_receiver_sb_cc_impl.cc:98-113).
+ *   - `*_host` calls take host pointers, stage H2D, launch, stage D2H and return when the
+ *     result is in `out` (the reference's synchronous generic_work contract).
+ *   - `*_device` calls take device pointers on the handle's device and only ENQUEUE work on
+ *     `stream` (a hipStream_t passed as void*, NULL = default stream).  No synchronisation,
+ *     no allocation: they are hipGraph-capturable.  Buffers must not alias.
+ *   - every function returns GFDM_HIP_OK (0) or a negative gfdm_hip_status; the text of the
+ *     last failure on the calling thread is available from gfdm_hip_last_error().
+ *   - a handle is not thread-safe (neither are the reference kernels, which own scratch
+ *     buffers: include/gfdm/receiver_kernel_cc.h:103-118); use one handle per thread/stream.
+ *   - there is NO CPU fallback: without a usable gfx950 device creation fails with
+ *     GFDM_HIP_ENODEV.
+ */
+#ifndef GFDM_HIP_H
+#define GFDM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gfdm_hip_status {
+    GFDM_HIP_OK = 0,
+    GFDM_HIP_EINVAL_TAPS = -1,     /* std::invalid_argument: taps.size() != timeslots*overlap
+                                      (lib/modulator_kernel_cc.cc:39-46, lib/receiver_kernel_cc.cc:40-47) */
+    GFDM_HIP_EINVAL_OVERLAP = -2,  /* std::invalid_argument: receiver overlap < 2 (lib/receiver_kernel_cc.cc:48-52) */
+    GFDM_HIP_EINVAL = -3,          /* any other bad argument (NULL pointer, negative size, bad subcarrier index ...) */
+    GFDM_HIP_ENODEV = -4,          /* no usable HIP device */
+    GFDM_HIP_EHIP = -5,            /* a HIP runtime call failed */
+    GFDM_HIP_ENOMEM = -6,
+    GFDM_HIP_EUNSUPPORTED = -7     /* block does not fit the device (LDS) */
+} gfdm_hip_status;
+
+/* how hard decisions are taken in the IC loop (gr::digital::constellation::decision_maker,
+ * called at lib/advanced_receiver_kernel_cc.cc:119) */
+typedef enum gfdm_hip_decision {
+    GFDM_HIP_DECIDE_AUTO = -1,     /* QPSK/BPSK sign tests when the points match those constellations, else NEAREST */
+    GFDM_HIP_DECIDE_NEAREST = 0,   /* minimum Euclidean distance, first minimum wins */
+    GFDM_HIP_DECIDE_QPSK = 1,      /* index = 2*(im > 0) + (re > 0)   (constellation_qpsk) */
+    GFDM_HIP_DECIDE_BPSK = 2       /* index = (re > 0)                (constellation_bpsk) */
+} gfdm_hip_decision;
+
+typedef struct gfdm_hip_modulator gfdm_hip_modulator;
+typedef struct gfdm_hip_receiver gfdm_hip_receiver;
+typedef struct gfdm_hip_advanced_receiver gfdm_hip_advanced_receiver;
+
+const char* gfdm_hip_strerror(int status);
+const char* gfdm_hip_last_error(void);
+int gfdm_hip_device_count(void);
+const char* gfdm_hip_version(void);
+
+/* ---- modulator_kernel_cc (include/gfdm/modulator_kernel_cc.h:41-51) -------------------- */
+
+/* ctor, lib/modulator_kernel_cc.cc:30-66.  taps: ntaps interleaved complex; device: HIP ordinal. */
+int gfdm_hip_modulator_create(gfdm_hip_modulator** out, int timeslots, int subcarriers, int overlap,
+                              const float* taps, int ntaps, int device);
+int gfdm_hip_modulator_destroy(gfdm_hip_modulator* m);
+int gfdm_hip_modulator_block_size(const gfdm_hip_modulator* m);                 /* block_size(), .h:50 */
+int gfdm_hip_modulator_filter_taps(const gfdm_hip_modulator* m, float* out);    /* filter_taps(), .cc:92-95; overlap*timeslots complex */
+const char* gfdm_hip_modulator_kernel_name(const gfdm_hip_modulator* m);        /* which HIP kernel family serves this shape */
+/* generic_work(out, in), lib/modulator_kernel_cc.cc:98-141, over nblocks blocks */
+int gfdm_hip_modulator_work_host(gfdm_hip_modulator* m, float* out, const float* in, int64_t nblocks);
+int gfdm_hip_modulator_work_device(gfdm_hip_modulator* m, void* out, const void* in, int64_t nblocks, void* stream);
+
+/* ---- receiver_kernel_cc (include/gfdm/receiver_kernel_cc.h:52-89) ---------------------- */
+
+/* ctor, lib/receiver_kernel_cc.cc:31-88 */
+int gfdm_hip_receiver_create(gfdm_hip_receiver** out, int timeslots, int subcarriers, int overlap,
+                             const float* taps, int ntaps, int device);
+int gfdm_hip_receiver_destroy(gfdm_hip_receiver* r);
+int gfdm_hip_receiver_block_size(const gfdm_hip_receiver* r);
+int gfdm_hip_receiver_timeslots(const gfdm_hip_receiver* r);
+int gfdm_hip_receiver_subcarriers(const gfdm_hip_receiver* r);
+int gfdm_hip_receiver_overlap(const gfdm_hip_receiver* r);
+int gfdm_hip_receiver_filter_taps(const gfdm_hip_receiver* r, float* out);      /* .cc:120-123 */
+int gfdm_hip_receiver_ic_filter_taps(const gfdm_hip_receiver* r, float* out);   /* .cc:125-128; timeslots complex */
+const char* gfdm_hip_receiver_kernel_name(const gfdm_hip_receiver* r);
+
+/* generic_work (f_eq == NULL, .cc:322-326) / generic_work_equalize (f_eq != NULL, .cc:328-334);
+ * f_eq holds one block_size vector PER BLOCK (lib/advanced_receiver_sb_cc_impl.cc:98-104) */
+int gfdm_hip_receiver_demodulate_host(gfdm_hip_receiver* r, float* out, const float* in, const float* f_eq, int64_t nblocks);
+int gfdm_hip_receiver_demodulate_device(gfdm_hip_receiver* r, void* out, const void* in, const void* f_eq, int64_t nblocks, void* stream);
+/* fft_filter_downsample (.cc:301-307) / fft_equalize_filter_downsample (.cc:309-320) */
+int gfdm_hip_receiver_fft_filter_downsample_host(gfdm_hip_receiver* r, float* out, const float* in, const float* f_eq, int64_t nblocks);
+int gfdm_hip_receiver_fft_filter_downsample_device(gfdm_hip_receiver* r, void* out, const void* in, const void* f_eq, int64_t nblocks, void* stream);
+/* transform_subcarriers_to_td (.cc:211-225) */
+int gfdm_hip_receiver_transform_subcarriers_to_td_host(gfdm_hip_receiver* r, float* out, const float* in, int64_t nblocks);
+int gfdm_hip_receiver_transform_subcarriers_to_td_device(gfdm_hip_receiver* r, void* out, const void* in, int64_t nblocks, void* stream);
+/* cancel_sc_interference(out, td_in, fd_in) (.cc:274-299) */
+int gfdm_hip_receiver_cancel_sc_interference_host(gfdm_hip_receiver* r, float* out, const float* td_in, const float* fd_in, int64_t nblocks);
+int gfdm_hip_receiver_cancel_sc_interference_device(gfdm_hip_receiver* r, void* out, const void* td_in, const void* fd_in, int64_t nblocks, void* stream);
+
+/* ---- advanced_receiver_kernel_cc (include/gfdm/advanced_receiver_kernel_cc.h:37-78) ---- */
+
+/* ctor, lib/advanced_receiver_kernel_cc.cc:32-52.  The gr::digital::constellation_sptr argument of the
+ * reference is passed as its points() array plus the decision rule. */
+int gfdm_hip_advanced_receiver_create(gfdm_hip_advanced_receiver** out, int timeslots, int subcarriers, int overlap,
+                                      const float* taps, int ntaps,
+                                      const int* subcarrier_map, int n_subcarrier_map,
+                                      int ic_iter,
+                                      const float* constellation_points, int n_points, int decision,
+                                      int do_phase_compensation, int device);
+int gfdm_hip_advanced_receiver_destroy(gfdm_hip_advanced_receiver* a);
+int gfdm_hip_advanced_receiver_block_size(const gfdm_hip_advanced_receiver* a);
+int gfdm_hip_advanced_receiver_set_ic(gfdm_hip_advanced_receiver* a, int ic_iter);                 /* .h:57 */
+int gfdm_hip_advanced_receiver_get_ic(const gfdm_hip_advanced_receiver* a);                        /* .h:58 */
+int gfdm_hip_advanced_receiver_set_phase_compensation(gfdm_hip_advanced_receiver* a, int enable);  /* .h:60-63 */
+int gfdm_hip_advanced_receiver_get_phase_compensation(const gfdm_hip_advanced_receiver* a);        /* .h:64 */
+const char* gfdm_hip_advanced_receiver_kernel_name(const gfdm_hip_advanced_receiver* a);
+/* generic_work (f_eq == NULL, .cc:93-98) / generic_work_equalize (f_eq != NULL, .cc:100-107) */
+int gfdm_hip_advanced_receiver_work_host(gfdm_hip_advanced_receiver* a, float* out, const float* in, const float* f_eq, int64_t nblocks);
+int gfdm_hip_advanced_receiver_work_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* f_eq, int64_t nblocks, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFDM_HIP_H */
