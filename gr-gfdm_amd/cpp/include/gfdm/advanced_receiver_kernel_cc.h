@@ -1,0 +1,76 @@
+/* gr::gfdm::advanced_receiver_kernel_cc -- interface of gr-gfdm's
+ * include/gfdm/advanced_receiver_kernel_cc.h:37-78 (receiver + interference cancellation),
+ * executed as ONE fused HIP kernel per batch behind include/gfdm_hip.h.
+ *
+ * Drop-in for lib/advanced_receiver_sb_cc_impl.cc:69-76,99,109.
+ */
+#ifndef INCLUDED_GFDM_ADVANCED_RECEIVER_KERNEL_CC_H
+#define INCLUDED_GFDM_ADVANCED_RECEIVER_KERNEL_CC_H
+
+#include <gfdm/constellation.h>
+#include <gfdm/gfdm_kernel_utils.h>
+
+#if defined(GFDM_WITH_GNURADIO) || (defined(__has_include) && __has_include(<gnuradio/digital/constellation.h>))
+#include <gnuradio/digital/constellation.h>
+#define GFDM_HAVE_GR_CONSTELLATION 1
+#endif
+
+struct gfdm_hip_advanced_receiver;
+
+namespace gr {
+namespace gfdm {
+
+#ifndef GFDM_HAVE_GR_CONSTELLATION
+typedef std::complex<float> gr_complex_t;
+#else
+typedef gr_complex gr_complex_t;
+#endif
+
+class GFDM_API advanced_receiver_kernel_cc
+{
+public:
+    /* argument order of the reference constructor; `constellation` carries points + decision rule */
+    advanced_receiver_kernel_cc(int timeslots,
+                                int subcarriers,
+                                int overlap,
+                                std::vector<gr_complex_t> frequency_taps,
+                                std::vector<int> subcarrier_map,
+                                int ic_iter,
+                                gr::gfdm::constellation_sptr constellation,
+                                int do_phase_compensation);
+#ifdef GFDM_HAVE_GR_CONSTELLATION
+    /* the reference signature: points() is read once, the decision rule is inferred from them */
+    advanced_receiver_kernel_cc(int timeslots, int subcarriers, int overlap, std::vector<gr_complex_t> frequency_taps,
+                                std::vector<int> subcarrier_map, int ic_iter, gr::digital::constellation_sptr constellation,
+                                int do_phase_compensation)
+        : advanced_receiver_kernel_cc(timeslots, subcarriers, overlap, frequency_taps, subcarrier_map, ic_iter,
+                                      gr::gfdm::constellation::from_points(constellation->points()), do_phase_compensation)
+    {
+    }
+#endif
+    ~advanced_receiver_kernel_cc();
+    advanced_receiver_kernel_cc(const advanced_receiver_kernel_cc&) = delete;
+    advanced_receiver_kernel_cc& operator=(const advanced_receiver_kernel_cc&) = delete;
+
+    void generic_work(gr_complex_t* p_out, const gr_complex_t* p_in);
+    void generic_work_equalize(gr_complex_t* out, const gr_complex_t* in, const gr_complex_t* f_eq_in);
+    void set_ic(int ic_iter);
+    int get_ic(void);
+    int block_size() { return d_block_len; }
+    void set_phase_compensation(int do_phase_compensation);
+    int get_phase_compensation();
+
+    /* --- additions: whole batches per call --- */
+    void generic_work_batch(gr_complex_t* out, const gr_complex_t* in, const gr_complex_t* f_eq_in, long nblocks);
+    void generic_work_device(void* d_out, const void* d_in, const void* d_f_eq, long nblocks, void* hip_stream);
+    const char* kernel_name() const;
+
+private:
+    int d_block_len;
+    gfdm_hip_advanced_receiver* d_handle;
+};
+
+} // namespace gfdm
+} // namespace gr
+
+#endif /* INCLUDED_GFDM_ADVANCED_RECEIVER_KERNEL_CC_H */

@@ -1,0 +1,185 @@
+// pybind11 module `gfdm_python`: the reference's kernel-level Python surface
+// (python/bindings/python_bindings.cc:52, modulator_python.cc:34-59, demodulator_python.cc:35-205)
+// on top of the GPU-backed classes, plus an AdvancedReceiver kernel binding and batched calls.
+// Unlike the reference module it does not import gnuradio.gr.
+#include <pybind11/complex.h>
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <gfdm/advanced_receiver_kernel_cc.h>
+#include <gfdm/modulator_kernel_cc.h>
+#include <gfdm/receiver_kernel_cc.h>
+
+namespace py = pybind11;
+using namespace gr::gfdm;
+
+typedef std::complex<float> cfloat;
+typedef py::array_t<cfloat, py::array::c_style | py::array::forcecast> carray;
+
+namespace {
+
+// The size/shape checks and their messages are part of the reference's behaviour
+// (python/bindings/modulator_python.cc:44-52, demodulator_python.cc:49-57,118-132).
+void require_1d(const py::buffer_info& a) { if (a.ndim != 1) throw std::runtime_error("Only ONE-dimensional vectors allowed!"); }
+
+void require_size(const py::buffer_info& a, int block_size, const char* what, const char* owner)
+{
+    if (a.size != block_size)
+        throw std::runtime_error(std::string(what) + " vector size(" + std::to_string(a.size) + ") MUST be equal to " + owner +
+                                 ".block_size(" + std::to_string(block_size) + ")!");
+}
+
+void require_batch(const py::buffer_info& a, int block_size, const char* what)
+{
+    if (block_size <= 0 || a.size % block_size)
+        throw std::runtime_error(std::string(what) + " size(" + std::to_string(a.size) + ") MUST be a multiple of block_size(" +
+                                 std::to_string(block_size) + ")!");
+}
+
+py::array_t<cfloat> like(const py::buffer_info& a) { return py::array_t<cfloat>(a.shape); }
+
+cfloat* ptr(py::buffer_info& b) { return static_cast<cfloat*>(b.ptr); }
+const cfloat* cptr(const py::buffer_info& b) { return static_cast<const cfloat*>(b.ptr); }
+
+// one-input single-block method of the demodulator (messages say "Modulator", as the reference does for these three)
+template <typename Fn>
+py::array_t<cfloat> rx_unary(receiver_kernel_cc& self, const carray& array, Fn fn)
+{
+    py::buffer_info in = array.request();
+    require_1d(in);
+    require_size(in, self.block_size(), "Input", "Modulator");
+    auto result = py::array_t<cfloat>(in.size);
+    py::buffer_info out = result.request();
+    fn(ptr(out), cptr(in));
+    return result;
+}
+
+template <typename Fn>
+py::array_t<cfloat> rx_binary(receiver_kernel_cc& self, const carray& array, const carray& second, Fn fn)
+{
+    py::buffer_info in = array.request(), in2 = second.request();
+    if (in.ndim != 1 || in2.ndim != 1) throw std::runtime_error("Only ONE-dimensional vectors allowed!");
+    require_size(in, self.block_size(), "Input", "Demodulator");
+    require_size(in2, self.block_size(), "Channel", "Demodulator");
+    auto result = py::array_t<cfloat>(in.size);
+    py::buffer_info out = result.request();
+    fn(ptr(out), cptr(in), cptr(in2));
+    return result;
+}
+
+} // namespace
+
+PYBIND11_MODULE(gfdm_python, m)
+{
+    m.doc() = "GFDM modulator / receiver kernels on AMD MI355X (HIP) behind gr-gfdm's kernel-class API";
+
+    py::class_<modulator_kernel_cc>(m, "Modulator")
+        .def(py::init<int, int, int, std::vector<cfloat>>(), py::arg("timeslots"), py::arg("subcarriers"), py::arg("overlap"),
+             py::arg("frequency_taps"))
+        .def("block_size", &modulator_kernel_cc::block_size)
+        .def("filter_taps", &modulator_kernel_cc::filter_taps)
+        .def("kernel_name", &modulator_kernel_cc::kernel_name)
+        .def("modulate",
+             [](modulator_kernel_cc& self, const carray array) {
+                 py::buffer_info in = array.request();
+                 require_1d(in);
+                 require_size(in, self.block_size(), "Input", "Modulator");
+                 auto result = py::array_t<cfloat>(in.size);
+                 py::buffer_info out = result.request();
+                 self.generic_work(ptr(out), cptr(in));
+                 return result;
+             })
+        .def("modulate_batch",
+             [](modulator_kernel_cc& self, const carray array) {
+                 py::buffer_info in = array.request();
+                 require_batch(in, self.block_size(), "Input");
+                 auto result = like(in);
+                 py::buffer_info out = result.request();
+                 self.generic_work_batch(ptr(out), cptr(in), in.size / self.block_size());
+                 return result;
+             },
+             "modulate any whole number of blocks (array of size nblocks*block_size, any shape) in one launch");
+
+    py::class_<receiver_kernel_cc>(m, "Demodulator")
+        .def(py::init<int, int, int, std::vector<cfloat>>(), py::arg("timeslots"), py::arg("subcarriers"), py::arg("overlap"),
+             py::arg("frequency_taps"))
+        .def("timeslots", &receiver_kernel_cc::timeslots)
+        .def("subcarriers", &receiver_kernel_cc::subcarriers)
+        .def("overlap", &receiver_kernel_cc::overlap)
+        .def("block_size", &receiver_kernel_cc::block_size)
+        .def("filter_taps", &receiver_kernel_cc::filter_taps)
+        .def("ic_filter_taps", &receiver_kernel_cc::ic_filter_taps)
+        .def("kernel_name", &receiver_kernel_cc::kernel_name)
+        .def("demodulate", [](receiver_kernel_cc& self, const carray a) {
+            return rx_unary(self, a, [&](cfloat* o, const cfloat* i) { self.generic_work(o, i); });
+        })
+        .def("fft_filter_downsample", [](receiver_kernel_cc& self, const carray a) {
+            return rx_unary(self, a, [&](cfloat* o, const cfloat* i) { self.fft_filter_downsample(o, i); });
+        })
+        .def("transform_subcarriers_to_td", [](receiver_kernel_cc& self, const carray a) {
+            return rx_unary(self, a, [&](cfloat* o, const cfloat* i) { self.transform_subcarriers_to_td(o, i); });
+        })
+        .def("demodulate_equalize", [](receiver_kernel_cc& self, const carray a, const carray eq) {
+            return rx_binary(self, a, eq, [&](cfloat* o, const cfloat* i, const cfloat* e) { self.generic_work_equalize(o, i, e); });
+        })
+        .def("fft_equalize_filter_downsample", [](receiver_kernel_cc& self, const carray a, const carray eq) {
+            return rx_binary(self, a, eq, [&](cfloat* o, const cfloat* i, const cfloat* e) { self.fft_equalize_filter_downsample(o, i, e); });
+        })
+        .def("cancel_sc_interference", [](receiver_kernel_cc& self, const carray td, const carray fd) {
+            return rx_binary(self, td, fd, [&](cfloat* o, const cfloat* i, const cfloat* e) { self.cancel_sc_interference(o, i, e); });
+        })
+        .def("demodulate_batch",
+             [](receiver_kernel_cc& self, const carray array, py::object eq) {
+                 py::buffer_info in = array.request();
+                 require_batch(in, self.block_size(), "Input");
+                 auto result = like(in);
+                 py::buffer_info out = result.request();
+                 if (eq.is_none()) {
+                     self.generic_work_batch(ptr(out), cptr(in), nullptr, in.size / self.block_size());
+                 } else {
+                     carray eq_arr = eq.cast<carray>();
+                     py::buffer_info e = eq_arr.request();
+                     if (e.size != in.size) throw std::runtime_error("Channel vector size(" + std::to_string(e.size) + ") MUST be equal to input size(" + std::to_string(in.size) + ")!");
+                     self.generic_work_batch(ptr(out), cptr(in), cptr(e), in.size / self.block_size());
+                 }
+                 return result;
+             },
+             py::arg("frames"), py::arg("f_eq") = py::none(), "demodulate any whole number of blocks; f_eq holds one vector per block");
+
+    py::class_<constellation, std::shared_ptr<constellation>>(m, "Constellation")
+        .def(py::init([](std::vector<cfloat> points) { return constellation::from_points(std::move(points)); }))
+        .def_static("qpsk", &constellation::qpsk)
+        .def_static("bpsk", &constellation::bpsk)
+        .def("points", &constellation::points)
+        .def("decision_maker", [](const constellation& c, cfloat s) { return c.decision_maker(&s); });
+
+    py::class_<advanced_receiver_kernel_cc>(m, "AdvancedReceiver")
+        .def(py::init<int, int, int, std::vector<cfloat>, std::vector<int>, int, constellation_sptr, int>(), py::arg("timeslots"),
+             py::arg("subcarriers"), py::arg("overlap"), py::arg("frequency_taps"), py::arg("subcarrier_map"), py::arg("ic_iter"),
+             py::arg("constellation"), py::arg("do_phase_compensation") = 0)
+        .def("block_size", &advanced_receiver_kernel_cc::block_size)
+        .def("set_ic", &advanced_receiver_kernel_cc::set_ic)
+        .def("get_ic", &advanced_receiver_kernel_cc::get_ic)
+        .def("set_phase_compensation", &advanced_receiver_kernel_cc::set_phase_compensation)
+        .def("get_phase_compensation", &advanced_receiver_kernel_cc::get_phase_compensation)
+        .def("kernel_name", &advanced_receiver_kernel_cc::kernel_name)
+        .def("demodulate",
+             [](advanced_receiver_kernel_cc& self, const carray array) {
+                 py::buffer_info in = array.request();
+                 require_batch(in, self.block_size(), "Input");
+                 auto result = like(in);
+                 py::buffer_info out = result.request();
+                 self.generic_work_batch(ptr(out), cptr(in), nullptr, in.size / self.block_size());
+                 return result;
+             })
+        .def("demodulate_equalize", [](advanced_receiver_kernel_cc& self, const carray array, const carray eq) {
+            py::buffer_info in = array.request(), e = eq.request();
+            require_batch(in, self.block_size(), "Input");
+            if (e.size != in.size) throw std::runtime_error("Channel vector size(" + std::to_string(e.size) + ") MUST be equal to input size(" + std::to_string(in.size) + ")!");
+            auto result = like(in);
+            py::buffer_info out = result.request();
+            self.generic_work_batch(ptr(out), cptr(in), cptr(e), in.size / self.block_size());
+            return result;
+        });
+}

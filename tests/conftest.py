@@ -1,0 +1,68 @@
+"""pytest configuration: markers, import paths, shared fixtures.
+
+`-m "not gpu"`: oracle vs golden vectors, host logic, C-ABI/pybind surface (no compute on a GPU).
+`-m gpu`:       parity of the HIP path (called through the C-ABI and the pybind11 module) with the oracle.
+Nothing here or in the gpu tests reads /root/reference.
+"""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "gr-gfdm_amd", "python"), os.path.join(ROOT, "gr-gfdm_amd", "lib"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    for k in ("M", "K", "L", "seed"):
+        g[k] = int(g[k])
+    g["alpha"] = float(g["alpha"])
+    return g
+
+
+@pytest.fixture(params=golden_names())
+def golden(request):
+    return load_golden(request.param)
+
+
+def rel_err(a, b):
+    """worst per-block relative L2 error of a against b (last axis = block)"""
+    a = np.asarray(a).reshape(-1, np.asarray(b).shape[-1]) if np.asarray(b).ndim > 1 else np.asarray(a)[None]
+    b = np.asarray(b).reshape(a.shape)
+    num = np.linalg.norm(a - b, axis=-1)
+    den = np.linalg.norm(b, axis=-1)
+    return float(np.max(num / np.maximum(den, 1e-30)))
+
+
+def max_abs_component(a, b):
+    d = np.asarray(a) - np.asarray(b)
+    return float(max(np.max(np.abs(d.real)), np.max(np.abs(d.imag))))
+
+
+def assert_places(a, b, places):
+    """gr_unittest.assertComplexTuplesAlmostEqual semantics: every |d re|, |d im| rounds to 0 at `places` decimals."""
+    assert max_abs_component(a, b) < 0.5 * 10.0 ** (-places), "max component error %.3e" % max_abs_component(a, b)
+
+
+def have_gpu():
+    try:
+        import gfdm_amd
+        return gfdm_amd.lib().gfdm_hip_device_count() > 0
+    except Exception:
+        return False

@@ -1,0 +1,97 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/gfdm_hip.h
+declares, argument validation mirrors the reference constructors, the pybind11 module has the reference's surface,
+and there is no CPU fallback (without a GPU every handle creation fails loudly)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, have_gpu
+
+HEADER = os.path.join(ROOT, "include", "gfdm_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gfdm_hip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import gfdm_amd
+    lib = ctypes.CDLL(gfdm_amd.capi.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 38
+    for n in names:
+        assert hasattr(lib, n), "libgfdm_hip.so does not export %s" % n
+    assert set(gfdm_amd.exported_symbols()) == set(names), "ctypes binding and header disagree"
+
+
+def test_strerror_and_version():
+    import gfdm_amd
+    L = gfdm_amd.lib()
+    assert L.gfdm_hip_strerror(0) == b"success"
+    assert b"overlap" in L.gfdm_hip_strerror(-2)
+    assert b"gfx950" in L.gfdm_hip_version()
+
+
+def test_constructor_validation_matches_reference():
+    """lib/modulator_kernel_cc.cc:39-46, lib/receiver_kernel_cc.cc:40-52: std::invalid_argument -> ValueError."""
+    import gfdm_amd
+    import gfdm_python
+    taps = np.ones(17, np.complex64)
+    for cls in (gfdm_amd.Modulator, gfdm_amd.Demodulator, gfdm_python.Modulator, gfdm_python.Demodulator):
+        with pytest.raises(ValueError, match=r"number of frequency taps\(17\) MUST be equal to n_timeslots\(9\) \* overlap\(2\) = 18!"):
+            cls(9, 64, 2, taps)
+    for cls in (gfdm_amd.Demodulator, gfdm_python.Demodulator):
+        with pytest.raises(ValueError, match="overlap MUST be greater or equal 2"):
+            cls(9, 64, 1, np.ones(9, np.complex64))
+    with pytest.raises(ValueError):
+        gfdm_python.AdvancedReceiver(9, 64, 2, taps, list(range(64)), 2, gfdm_python.Constellation.qpsk(), 0)
+
+
+def test_pybind_surface_matches_reference():
+    """python/bindings/modulator_python.cc:34-59, demodulator_python.cc:35-205."""
+    import gfdm_python
+    for name in ("block_size", "filter_taps", "modulate"):
+        assert hasattr(gfdm_python.Modulator, name)
+    for name in ("timeslots", "subcarriers", "overlap", "block_size", "filter_taps", "demodulate", "fft_filter_downsample",
+                 "transform_subcarriers_to_td", "demodulate_equalize", "fft_equalize_filter_downsample", "cancel_sc_interference"):
+        assert hasattr(gfdm_python.Demodulator, name)
+    for name in ("block_size", "set_ic", "get_ic", "set_phase_compensation", "get_phase_compensation", "demodulate", "demodulate_equalize"):
+        assert hasattr(gfdm_python.AdvancedReceiver, name)
+    q = gfdm_python.Constellation.qpsk()
+    pts = np.array(q.points())
+    assert np.allclose(pts, np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) / np.sqrt(2))
+    assert [q.decision_maker(p) for p in pts] == [0, 1, 2, 3]
+    assert q.decision_maker(0j) == 0                        # zero maps to the negative point (sign test is '> 0')
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must refuse to run (never silently compute on the host)."""
+    if have_gpu():
+        pytest.skip("a GPU is present")
+    import gfdm_amd
+    import gfdm_python
+    taps = np.ones(18, np.complex64)
+    with pytest.raises(gfdm_amd.GfdmHipError) as e:
+        gfdm_amd.Modulator(9, 64, 2, taps)
+    assert e.value.status == gfdm_amd.capi.ENODEV
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        gfdm_python.Demodulator(9, 64, 2, taps)
+
+
+def test_product_sources_do_not_touch_the_oracle():
+    """The oracle is test infrastructure: nothing under gr-gfdm_amd/ or include/ may reference it."""
+    bad = []
+    for base in (os.path.join(ROOT, "gr-gfdm_amd"), os.path.join(ROOT, "include")):
+        for dirpath, _, files in os.walk(base):
+            for f in files:
+                if f.endswith((".so", ".o", ".pyc")):
+                    continue
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"gfdm_oracle|gfdm_ref|c_oracle|oracle/", text):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

@@ -1,0 +1,146 @@
+"""CPU tests of the oracle itself: both restatements (numpy float64, plain C float32) against the pygfdm golden
+vectors and against the known-answer properties the reference's own tests assert."""
+import numpy as np
+import pytest
+
+import c_oracle
+import gfdm_ref as R
+from conftest import assert_places, load_golden, rel_err
+from gfdm_amd.filters import get_frequency_domain_filter
+
+TOL_F64 = 1e-12     # numpy oracle vs pygfdm (both float64)
+TOL_F32 = 1e-5      # north_star tolerance: relative L2 per block, float32 path vs reference
+
+
+def test_numpy_oracle_matches_pygfdm_modulator(golden):
+    g = golden
+    nt = R.normalize_taps(g["taps"], g["M"])
+    for sym, ref in ((g["symbols"], g["pygfdm_modulate"]), (g["gauss_symbols"], g["pygfdm_modulate_gauss"])):
+        assert rel_err(R.modulate(sym, nt, g["M"], g["K"], g["L"]), ref) < TOL_F64
+
+
+def test_numpy_oracle_matches_pygfdm_receiver(golden):
+    g = golden
+    if g["L"] != 2:
+        pytest.skip("pygfdm's receiver is only valid for overlap 2 (python/pygfdm/gfdm_receiver.py:54,207)")
+    nt = R.normalize_taps(g["taps"], g["M"])
+    assert rel_err(R.demodulate(g["pygfdm_modulate"], nt, g["M"], g["K"], g["L"]), g["pygfdm_demodulate"]) < TOL_F64
+    assert rel_err(R.demodulate(g["gauss_symbols"], nt, g["M"], g["K"], g["L"]), g["pygfdm_demodulate_gauss"]) < TOL_F64
+
+
+def test_c_oracle_matches_pygfdm(golden):
+    g = golden
+    o = c_oracle.COracle(g["M"], g["K"], g["L"], g["taps"])
+    got = o.modulate(g["symbols"])
+    assert rel_err(got, g["pygfdm_modulate"]) < TOL_F32
+    assert_places(got, g["pygfdm_modulate"], 5)                  # qa_python_bindings.py:273,294
+    assert rel_err(o.modulate(g["gauss_symbols"]), g["pygfdm_modulate_gauss"]) < TOL_F32
+    if g["L"] == 2:
+        dem = o.demodulate(g["pygfdm_modulate"])
+        assert rel_err(dem, g["pygfdm_demodulate"]) < TOL_F32
+        assert_places(dem, g["pygfdm_demodulate"], 5)            # qa_python_bindings.py:341,363
+        assert rel_err(o.demodulate(g["gauss_symbols"]), g["pygfdm_demodulate_gauss"]) < TOL_F32
+
+
+def test_c_oracle_matches_numpy_oracle_all_stages(golden):
+    g = golden
+    M, K, L = g["M"], g["K"], g["L"]
+    o = c_oracle.COracle(M, K, L, g["taps"])
+    nt = R.normalize_taps(g["taps"], M)
+    assert rel_err(o.filter_taps(), nt) < 1e-6
+    assert rel_err(o.ic_filter_taps(), R.ic_filter_taps(nt, M, L)) < 1e-6
+    x, feq = g["frame_through_channel"], g["f_eq"]
+    S = R.fft_filter_downsample(x, nt, M, K, L, feq)
+    assert rel_err(o.fft_filter_downsample(x, feq), S) < TOL_F32
+    assert rel_err(o.transform_subcarriers_to_td(S), R.transform_subcarriers_to_td(S, M, K)) < TOL_F32
+    assert rel_err(o.cancel_sc_interference(g["symbols"], S), R.cancel_sc_interference(g["symbols"], S, R.ic_filter_taps(nt, M, L), M, K)) < TOL_F32
+    assert rel_err(o.demodulate(x, feq), R.demodulate(x, nt, M, K, L, feq)) < TOL_F32
+    for pc in (0, 1):
+        ref = R.advanced_receive(x, nt, M, K, L, g["smap"], R.qpsk_points(), 2, f_eq=feq, kind="qpsk", do_phase_compensation=pc)
+        assert rel_err(o.advanced_receive(x, g["smap"], R.qpsk_points(), 2, f_eq=feq, kind="qpsk", do_phase_compensation=pc), ref) < TOL_F32
+        assert rel_err(o.advanced_receive(x, g["smap"], R.qpsk_points(), 2, f_eq=feq, kind="nearest", do_phase_compensation=pc), ref) < TOL_F32
+
+
+def test_equalizer_undoes_channel(golden):
+    """qa_python_bindings.py:365-386 generalised: demodulate_equalize(frame * H, H) == demodulate(frame)."""
+    g = golden
+    nt = R.normalize_taps(g["taps"], g["M"])
+    a = R.demodulate(g["frame_through_channel"], nt, g["M"], g["K"], g["L"], g["f_eq"])
+    b = R.demodulate(g["pygfdm_modulate"], nt, g["M"], g["K"], g["L"])
+    assert rel_err(a, b) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["cfg4_k128_m15_l4", "ref_m127_k16_l4", "cfg2_k64_m9", "ref_m16_k4"])
+def test_receiver_is_transpose_of_modulator(name):
+    """The only pin of the receiver at overlap != 2: with A(t) the modulator matrix (pinned by pygfdm at any
+    overlap) the receiver matrix is R(t) = (N/M) * A(t)^T (plain transpose), because the fold
+    (receiver_kernel_cc.cc:165-192) is the transpose of the scatter (modulator_kernel_cc.cc:116-132) and the
+    DFT matrices are symmetric with ifft = conj(fft)/n.  Checked as a bilinear identity on random vectors."""
+    g = load_golden(name)
+    M, K, L = g["M"], g["K"], g["L"]
+    N = M * K
+    nt = R.normalize_taps(g["taps"], M)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    d = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    # R = (1/M) (I x conj F_M) G^T F_N and A = (1/N) conj(F_N) G (I x F_M)  =>  conj(R(t)) = (N/M) A(conj t)^T
+    lhs = np.sum(np.conj(R.demodulate(x, nt, M, K, L)) * d)
+    rhs = (N / M) * np.sum(np.conj(x) * R.modulate(d, np.conj(nt), M, K, L))
+    assert abs(lhs - rhs) / abs(lhs) < 1e-11
+
+
+def test_ic_genie_known_answer():
+    """qa_python_bindings.py:388-415: after two genie cancellations the demodulated symbols equal the data to 1 place."""
+    g = load_golden("ref_m5_k32_a35")
+    M, K, L = g["M"], g["K"], g["L"]
+    nt = R.normalize_taps(g["taps"], M)
+    o = c_oracle.COracle(M, K, L, g["taps"])
+    data, frame = g["symbols"], g["pygfdm_modulate"]
+    for impl in ("numpy", "c"):
+        if impl == "numpy":
+            fd = R.fft_filter_downsample(frame, nt, M, K, L)
+            res = R.transform_subcarriers_to_td(R.cancel_sc_interference(data, fd, R.ic_filter_taps(nt, M, L), M, K), M, K)
+        else:
+            fd = o.fft_filter_downsample(frame)
+            res = o.transform_subcarriers_to_td(o.cancel_sc_interference(data, fd))
+        assert_places(res, data, 1)
+
+
+@pytest.mark.parametrize("name,ic,places", [("ref_m9_k64_a100", 64, 2), ("ref_m9_k32_act20", 64, 1), ("cfg2_k64_m9", 2, 1)])
+def test_ic_loopback_converges(name, ic, places):
+    """qa_advanced_receiver_sb_cc.py:84-119 (2 places) and :134-172 (1 place, 20 active subcarriers, data scaled by 2)."""
+    g = load_golden(name)
+    M, K, L = g["M"], g["K"], g["L"]
+    nt = R.normalize_taps(g["taps"], M)
+    scale = 2.0 if name == "ref_m9_k32_act20" else 1.0
+    data = g["symbols"] * scale
+    frame = R.modulate(data, nt, M, K, L)
+    o = c_oracle.COracle(M, K, L, g["taps"])
+    for res in (R.advanced_receive(frame, nt, M, K, L, g["smap"], R.qpsk_points(), ic, kind="qpsk"),
+                o.advanced_receive(frame, g["smap"], R.qpsk_points(), ic, kind="qpsk")):
+        res = res.reshape(-1, K, M)[:, g["smap"], :]
+        ref = data.reshape(-1, K, M)[:, g["smap"], :]
+        if scale == 1.0:
+            assert_places(res, ref, places)
+        else:   # decisions are unit-energy QPSK, so the cancelled interference is that of unit symbols; signs must match
+            assert np.all(np.sign(res.real) == np.sign(ref.real)) and np.all(np.sign(res.imag) == np.sign(ref.imag))
+
+
+def test_advanced_receiver_with_zero_iterations_is_plain_receiver():
+    """qa_advanced_receiver_sb_cc.py:45-82."""
+    g = load_golden("ref_m127_k16_l2")
+    nt = R.normalize_taps(g["taps"], g["M"])
+    a = R.advanced_receive(g["gauss_symbols"], nt, g["M"], g["K"], g["L"], np.arange(g["K"]), R.qpsk_points(), 0)
+    assert rel_err(a, g["pygfdm_demodulate_gauss"]) < TOL_F64
+
+
+def test_tap_normalisation_and_validation():
+    M, K, L = 25, 96, 2                                          # qa_python_bindings.py:304-319
+    taps = get_frequency_domain_filter("rrc", 0.35, M, K, L)
+    o = c_oracle.COracle(M, K, L, taps)
+    assert_places(o.filter_taps(), taps, 6)                     # already energy-M normalised -> unchanged
+    assert abs(np.sum(np.abs(o.filter_taps()) ** 2) - M) < 1e-4
+    o3 = c_oracle.COracle(M, K, L, 3.0 * taps)
+    assert rel_err(o3.filter_taps(), taps) < 1e-6
+    with pytest.raises(ValueError):
+        c_oracle.COracle(M, K, L, taps[:-1])

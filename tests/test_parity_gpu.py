@@ -1,0 +1,331 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (ctypes, host and device entry points) and through
+the pybind11 module `gfdm_python`, against the CPU oracle and the committed pygfdm golden vectors.
+
+Tolerance (BASELINE.json north_star): relative L2 error per block <= 1e-5 against the float64 oracle; where the
+reference's own tests state decimal places (python/qa_python_bindings.py) those are asserted as well.
+IC outputs are compared only on blocks whose oracle decision margin exceeds DECISION_GUARD: a hard decision taken
+on a component closer to zero than fp32 noise may legitimately flip.
+"""
+import numpy as np
+import pytest
+
+import c_oracle
+import gfdm_ref as R
+from conftest import assert_places, golden_names, have_gpu, load_golden, rel_err
+from gfdm_amd.filters import get_frequency_domain_filter
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+DECISION_GUARD = 1e-4
+
+# (M, K, L, alpha): BASELINE.json configs 1-5 and the shapes of the reference's tests
+SHAPES = [(5, 32, 2, 0.5), (9, 64, 2, 0.2), (15, 128, 4, 0.2), (31, 256, 2, 0.1),
+          (16, 4, 2, 0.35), (21, 128, 2, 0.35), (8, 4, 2, 0.5), (127, 16, 4, 0.5), (127, 16, 2, 0.5), (9, 32, 2, 0.5),
+          (25, 96, 2, 0.35), (7, 6, 2, 0.3), (3, 10, 6, 0.3), (4, 16, 3, 0.4)]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    if not have_gpu():
+        pytest.fail("no MI355X visible: the HIP path cannot run (there is no CPU fallback to test instead)")
+
+
+def qpsk(rng, shape):
+    return ((1 - 2 * rng.integers(0, 2, shape)) + 1j * (1 - 2 * rng.integers(0, 2, shape))) / np.sqrt(2)
+
+
+def guarded(ref_stages, smap, K, M):
+    """blocks whose every decided component (all IC iterations) is at least DECISION_GUARD away from zero"""
+    keep = None
+    for d in [ref_stages["d0"]] + ref_stages["iters"][:-1]:
+        v = d.reshape(-1, K, M)[:, smap, :]
+        ok = (np.minimum(np.abs(v.real), np.abs(v.imag)).reshape(v.shape[0], -1).min(axis=1) > DECISION_GUARD)
+        keep = ok if keep is None else (keep & ok)
+    return keep
+
+
+# ---------------------------------------------------------------- golden vectors, pybind11 surface
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_modulator(name):
+    import gfdm_python
+    g = load_golden(name)
+    mod = gfdm_python.Modulator(g["M"], g["K"], g["L"], g["taps"])
+    for sym, ref in ((g["symbols"], g["pygfdm_modulate"]), (g["gauss_symbols"], g["pygfdm_modulate_gauss"])):
+        for b in range(sym.shape[0]):
+            res = mod.modulate(sym[b])                      # complex128 in, forcecast, as the reference tests do
+            assert res.dtype == np.complex64 and res.shape == (g["M"] * g["K"],)
+            assert rel_err(res, ref[b]) < TOL
+        assert rel_err(mod.modulate_batch(sym), ref) < TOL
+    assert_places(mod.modulate(g["symbols"][0]), g["pygfdm_modulate"][0], 5)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if "_l4" not in n])
+def test_golden_demodulator(name):
+    import gfdm_python
+    g = load_golden(name)
+    dem = gfdm_python.Demodulator(g["M"], g["K"], g["L"], g["taps"])
+    for frame, ref in ((g["pygfdm_modulate"], g["pygfdm_demodulate"]), (g["gauss_symbols"], g["pygfdm_demodulate_gauss"])):
+        for b in range(frame.shape[0]):
+            assert rel_err(dem.demodulate(frame[b]), ref[b]) < TOL
+        assert rel_err(dem.demodulate_batch(frame), ref) < TOL
+    assert_places(dem.demodulate(g["pygfdm_modulate"][0]), g["pygfdm_demodulate"][0], 5)
+    # equaliser: qa_python_bindings.py:365-386 with a frequency-selective channel instead of a flat phase
+    got = dem.demodulate_equalize(g["frame_through_channel"][0], g["f_eq"][0])
+    assert rel_err(got, g["pygfdm_demodulate"][0]) < TOL
+    assert rel_err(dem.demodulate_batch(g["frame_through_channel"], g["f_eq"]), g["pygfdm_demodulate"]) < TOL
+
+
+# ---------------------------------------------------------------- the reference's own binding tests, restated
+
+def test_ref_demodulator_init():
+    """qa_python_bindings.py:304-319 (K = 96 is not a power of two)."""
+    import gfdm_python
+    M, K, L = 25, 96, 2
+    taps = get_frequency_domain_filter("rrc", 0.35, M, K, L)
+    demod = gfdm_python.Demodulator(M, K, L, taps)
+    assert (demod.timeslots(), demod.subcarriers(), demod.overlap(), demod.block_size()) == (M, K, L, M * K)
+    assert_places(np.array(demod.filter_taps()), taps, 6)
+
+
+def test_ref_demodulator_flat_phase_equalize():
+    """qa_python_bindings.py:365-386."""
+    import gfdm_python
+    g = load_golden("ref_m21_k128")
+    dem = gfdm_python.Demodulator(g["M"], g["K"], g["L"], g["taps"])
+    frame, ref = g["pygfdm_modulate"][0], g["pygfdm_demodulate"][0]
+    res = dem.demodulate_equalize(frame * np.exp(1j), np.ones(ref.size, ref.dtype) * np.exp(1j))
+    assert_places(res, ref, 5)
+
+
+def test_ref_steps_and_genie_ic():
+    """qa_python_bindings.py:388-440."""
+    import gfdm_python
+    g = load_golden("ref_m5_k32_a35")
+    dem = gfdm_python.Demodulator(g["M"], g["K"], g["L"], g["taps"])
+    data, frame, ref = g["symbols"][0], g["pygfdm_modulate"][0], g["pygfdm_demodulate"][0]
+    fd_res = dem.fft_filter_downsample(frame)
+    assert_places(dem.transform_subcarriers_to_td(fd_res), ref, 5)
+    for _ in range(2):
+        res = dem.transform_subcarriers_to_td(dem.cancel_sc_interference(data, fd_res))
+    assert_places(res, data, 1)
+    eq = np.ones(ref.size, ref.dtype) * np.exp(1j)
+    fd_eq = dem.fft_equalize_filter_downsample(frame * np.exp(1j), eq)
+    assert_places(dem.transform_subcarriers_to_td(fd_eq), ref, 5)
+
+
+def test_ref_binding_error_messages():
+    """python/bindings/modulator_python.cc:44-52, demodulator_python.cc:49-57,118-132."""
+    import gfdm_python
+    taps = get_frequency_domain_filter("rrc", 0.5, 5, 32, 2)
+    mod, dem = gfdm_python.Modulator(5, 32, 2, taps), gfdm_python.Demodulator(5, 32, 2, taps)
+    with pytest.raises(RuntimeError, match="Only ONE-dimensional vectors allowed!"):
+        mod.modulate(np.zeros((2, 80), np.complex64))
+    with pytest.raises(RuntimeError, match=r"Input vector size\(159\) MUST be equal to Modulator.block_size\(160\)!"):
+        mod.modulate(np.zeros(159, np.complex64))
+    with pytest.raises(RuntimeError, match=r"Input vector size\(161\) MUST be equal to Modulator.block_size\(160\)!"):
+        dem.demodulate(np.zeros(161, np.complex64))
+    with pytest.raises(RuntimeError, match=r"Channel vector size\(10\) MUST be equal to Demodulator.block_size\(160\)!"):
+        dem.demodulate_equalize(np.zeros(160, np.complex64), np.ones(10, np.complex64))
+    with pytest.raises(RuntimeError, match="Only ONE-dimensional vectors allowed!"):
+        dem.cancel_sc_interference(np.zeros((160, 1), np.complex64), np.zeros(160, np.complex64))
+
+
+def test_ref_advanced_receiver_loopbacks():
+    """qa_advanced_receiver_sb_cc.py:45-82 (ic=0 equals plain receiver, 4 places), :84-119 (alpha=1, ic=64, 2 places),
+    :121-132 (set_ic/get_ic), :134-172 (20 active subcarriers, data*2, ic=64: signs recovered)."""
+    import gfdm_python
+    qp = gfdm_python.Constellation.qpsk()
+    g = load_golden("ref_m127_k16_l2")
+    M, K, L = g["M"], g["K"], g["L"]
+    adv = gfdm_python.AdvancedReceiver(M, K, L, g["taps"], list(range(K)), 0, qp, 0)
+    assert_places(adv.demodulate_equalize(g["gauss_symbols"], np.ones_like(g["gauss_symbols"])), g["pygfdm_demodulate_gauss"], 4)
+
+    g = load_golden("ref_m9_k64_a100")
+    M, K, L = g["M"], g["K"], g["L"]
+    mod = gfdm_python.Modulator(M, K, L, g["taps"])
+    adv = gfdm_python.AdvancedReceiver(M, K, L, g["taps"], list(range(K)), 64, qp, 0)
+    assert_places(adv.demodulate(mod.modulate_batch(g["symbols"])), g["symbols"], 2)
+
+    g = load_golden("ref_m9_k32_act20")
+    M, K, L = g["M"], g["K"], g["L"]
+    adv = gfdm_python.AdvancedReceiver(M, K, L, g["taps"], g["smap"].tolist(), 64, qp, 0)
+    adv.set_ic(2)
+    assert adv.get_ic() == 2
+    adv.set_ic(64)
+    adv.set_phase_compensation(1)
+    assert adv.get_phase_compensation() == 1
+    adv.set_phase_compensation(0)
+    mod = gfdm_python.Modulator(M, K, L, g["taps"])
+    data = 2.0 * g["symbols"]
+    res = adv.demodulate(mod.modulate_batch(data)).reshape(-1, K, M)[:, g["smap"], :]
+    ref = data.reshape(-1, K, M)[:, g["smap"], :]
+    assert np.all(np.sign(res.real) == np.sign(ref.real)) and np.all(np.sign(res.imag) == np.sign(ref.imag))
+
+
+# ---------------------------------------------------------------- oracle parity, every entry point, every shape
+
+@pytest.mark.parametrize("M,K,L,alpha", SHAPES)
+def test_every_entry_point_against_oracle(M, K, L, alpha):
+    import gfdm_amd
+    rng = np.random.default_rng(1000 * M + K + L)
+    taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    N, B = M * K, 7
+    mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    assert rel_err(mod.filter_taps(), nt) < 1e-6 and rel_err(dem.filter_taps(), nt) < 1e-6
+    assert rel_err(dem.ic_filter_taps(), R.ic_filter_taps(nt, M, L)) < 1e-6
+    d = qpsk(rng, (B, N))
+    x = R.modulate(d, nt, M, K, L)
+    assert rel_err(mod.modulate(d), x) < TOL
+    gauss = rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N))
+    assert rel_err(mod.modulate(gauss), R.modulate(gauss, nt, M, K, L)) < TOL
+    feq = np.fft.fft(np.array([1, .5, .1j, .1 + .05j]), N)[None, :] * np.exp(0.01j * np.arange(B))[:, None]
+    xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
+    S = R.fft_filter_downsample(x, nt, M, K, L)
+    assert rel_err(dem.fft_filter_downsample(x), S) < TOL
+    assert rel_err(dem.fft_equalize_filter_downsample(xe, feq), R.fft_filter_downsample(xe, nt, M, K, L, feq)) < TOL
+    assert rel_err(dem.transform_subcarriers_to_td(S), R.transform_subcarriers_to_td(S, M, K)) < TOL
+    assert rel_err(dem.cancel_sc_interference(d, S), R.cancel_sc_interference(d, S, R.ic_filter_taps(nt, M, L), M, K)) < TOL
+    assert rel_err(dem.demodulate(x), R.demodulate(x, nt, M, K, L)) < TOL
+    assert rel_err(dem.demodulate(gauss), R.demodulate(gauss, nt, M, K, L)) < TOL
+    assert rel_err(dem.demodulate_equalize(xe, feq), R.demodulate(xe, nt, M, K, L, feq)) < TOL
+    # and the plain-C float32 oracle agrees with the GPU to float32 noise as well
+    co = c_oracle.COracle(M, K, L, taps)
+    assert rel_err(dem.demodulate_equalize(xe, feq), co.demodulate(xe, feq)) < TOL
+
+
+@pytest.mark.parametrize("M,K,L,alpha", SHAPES)
+@pytest.mark.parametrize("pc", [0, 1])
+def test_advanced_receiver_against_oracle(M, K, L, alpha, pc):
+    import gfdm_amd
+    rng = np.random.default_rng(77 * M + K + L + pc)
+    taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    N, B = M * K, 6
+    smap = np.arange(K) if K < 8 else np.concatenate((np.arange(1, K // 2 - 1), np.arange(K // 2 + 2, K)))
+    d = np.zeros((B, K, M), complex)
+    d[:, smap, :] = qpsk(rng, (B, len(smap), M))
+    x = R.modulate(d.reshape(B, N), nt, M, K, L)
+    feq = np.fft.fft(np.array([1, .5, .1j, .1 + .05j]), N)[None, :] * np.exp(0.01j * np.arange(B))[:, None]
+    xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
+    checked = 0
+    for ic_iter in (0, 1, 2, 5):
+        for kind, pts in (("qpsk", R.qpsk_points()), ("nearest", R.qpsk_points() * np.exp(0.1j))):
+            adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, ic_iter, pts, do_phase_compensation=pc,
+                                            decision="auto" if kind == "qpsk" else "nearest")
+            ref, st = R.advanced_receive(xe, nt, M, K, L, smap, pts, ic_iter, f_eq=feq, do_phase_compensation=pc, kind=kind,
+                                         return_stages=True)
+            got = adv.demodulate_equalize(xe, feq)
+            keep = guarded(st, smap, K, M) if ic_iter > 0 else np.ones(B, bool)
+            checked += int(keep.sum())
+            assert rel_err(got[keep], ref[keep]) < (TOL if pc == 0 else 5 * TOL)
+            ref0 = R.advanced_receive(x, nt, M, K, L, smap, pts, ic_iter, do_phase_compensation=pc, kind=kind)
+            got0 = adv.demodulate(x)
+            assert rel_err(got0[keep], ref0[keep]) < (TOL if pc == 0 else 5 * TOL) or ic_iter > 0
+    assert checked >= 6 * B        # the guard may drop a few blocks, never most of them
+
+
+# ---------------------------------------------------------------- device-pointer (batched, asynchronous) entry points
+
+@pytest.mark.parametrize("M,K,L,alpha", SHAPES[:4])
+def test_device_entry_points_match_host_entry_points(M, K, L, alpha):
+    import torch
+    import gfdm_amd
+    from gfdm_amd import synth
+    dev = torch.device("cuda:0")
+    taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+    N, B = M * K, 33
+    mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+    sym = synth.qpsk_symbols(5, B, N, dev)
+    feq = synth.channel_response(5, B, N, dev)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        x = mod.modulate(sym)
+        xe = synth.through_channel(x, feq)
+        outs = [dem.demodulate(x), dem.demodulate_equalize(xe, feq), dem.fft_filter_downsample(x),
+                dem.fft_equalize_filter_downsample(xe, feq), adv.demodulate(x), adv.demodulate_equalize(xe, feq)]
+        S = outs[2]
+        outs += [dem.transform_subcarriers_to_td(S), dem.cancel_sc_interference(sym, S)]
+    stream.synchronize()
+    sym_h, x_h, xe_h, feq_h, S_h = (t.cpu().numpy() for t in (sym, x, xe, feq, S))
+    host = [dem.demodulate(x_h), dem.demodulate_equalize(xe_h, feq_h), dem.fft_filter_downsample(x_h),
+            dem.fft_equalize_filter_downsample(xe_h, feq_h), adv.demodulate(x_h), adv.demodulate_equalize(xe_h, feq_h),
+            dem.transform_subcarriers_to_td(S_h), dem.cancel_sc_interference(sym_h, S_h)]
+    assert np.array_equal(mod.modulate(sym_h), x_h)
+    for d_out, h_out in zip(outs, host):
+        assert np.array_equal(d_out.cpu().numpy(), h_out)       # same kernels, same inputs: bit-identical
+    nt = R.normalize_taps(taps, M)
+    assert rel_err(x_h, R.modulate(sym_h, nt, M, K, L)) < TOL
+
+
+def test_empty_and_ragged_batches():
+    import gfdm_amd
+    taps = get_frequency_domain_filter("rrc", 0.2, 9, 64, 2)
+    mod, dem = gfdm_amd.Modulator(9, 64, 2, taps), gfdm_amd.Demodulator(9, 64, 2, taps)
+    assert mod.modulate(np.zeros((0, 576), np.complex64)).shape == (0, 576)
+    assert dem.demodulate(np.zeros(0, np.complex64)).shape == (0,)
+    with pytest.raises(RuntimeError, match="multiple of block_size"):
+        mod.modulate(np.zeros(577, np.complex64))
+    rng = np.random.default_rng(3)
+    nt = R.normalize_taps(taps, 9)
+    for B in (1, 2, 3, 5, 63, 64, 65, 257):                    # batch sizes that do not fill a workgroup / wave evenly
+        d = qpsk(rng, (B, 576))
+        x = mod.modulate(d)
+        assert rel_err(x, R.modulate(d, nt, 9, 64, 2)) < TOL
+        assert rel_err(dem.demodulate(x), R.demodulate(x, nt, 9, 64, 2)) < TOL
+
+
+# ---------------------------------------------------------------- full BASELINE sizes: size-independent properties
+
+FULL = [("cfg2", 9, 64, 2, 0.2, 4096), ("cfg4", 15, 128, 4, 0.2, 8192), ("cfg5", 31, 256, 2, 0.1, 2048)]
+
+
+@pytest.mark.parametrize("name,M,K,L,alpha,B", FULL)
+def test_full_size_properties(name, M, K, L, alpha, B):
+    """At BASELINE batch sizes the float64 oracle is too slow to run everywhere, so check (1) random blocks against
+    the oracle, (2) linearity of modulator and receiver, (3) the transpose identity between them, (4) IC loop-back
+    recovers the transmitted QPSK symbols, (5) equaliser round trip."""
+    import torch
+    import gfdm_amd
+    from gfdm_amd import synth
+    dev = torch.device("cuda:0")
+    N = M * K
+    taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+    sym = synth.qpsk_symbols(0, B, N, dev)
+    feq = synth.channel_response(0, B, N, dev)
+    x = mod.modulate(sym)
+    y = dem.demodulate(x)
+    xe = synth.through_channel(x, feq)
+    ye = dem.demodulate_equalize(xe, feq)
+    z = adv.demodulate_equalize(xe, feq)
+    torch.cuda.synchronize()
+    pick = np.unique(np.concatenate(([0, 1, B - 1], np.random.default_rng(5).integers(0, B, 13))))
+    sym_h = sym[pick].cpu().numpy()
+    assert rel_err(x[pick].cpu().numpy(), R.modulate(sym_h, nt, M, K, L)) < TOL
+    assert rel_err(y[pick].cpu().numpy(), R.demodulate(x[pick].cpu().numpy(), nt, M, K, L)) < TOL
+    ref_ic = R.advanced_receive(xe[pick].cpu().numpy(), nt, M, K, L, np.arange(K), R.qpsk_points(), 2, f_eq=feq[pick].cpu().numpy(), kind="qpsk")
+    assert rel_err(z[pick].cpu().numpy(), ref_ic) < TOL
+    # equaliser round trip over the whole batch (fp32 channel application + division: 1e-4 is its own noise floor)
+    assert float((ye - y).abs().max() / y.abs().max()) < 1e-4
+    # IC loop-back: every symbol of every block lands on the transmitted constellation point's quadrant and close to it
+    assert bool(torch.all(torch.sign(z.real) == torch.sign(sym.real))) and bool(torch.all(torch.sign(z.imag) == torch.sign(sym.imag)))
+    assert float((z - sym).abs().max()) < 0.2
+    # linearity: demod(a*x1 + b*x2) == a*demod(x1) + b*demod(x2)
+    half = B // 2
+    a, b = 0.75 - 0.5j, -1.25 + 0.25j
+    mix = (a * x[:half] + b * x[half:2 * half]).contiguous()
+    lin = dem.demodulate(mix)
+    assert float((lin - (a * y[:half] + b * y[half:2 * half])).abs().max() / y.abs().max()) < 2e-5
+    # transpose identity on the device results: <conj(R x), d> == (N/M) <conj(x), A_conj d>
+    modc = gfdm_amd.Modulator(M, K, L, np.conj(taps))
+    g = torch.randn(B, N, dtype=torch.complex64, device=dev)
+    w = torch.randn(B, N, dtype=torch.complex64, device=dev)
+    lhs = (dem.demodulate(g).conj().to(torch.complex128) * w).sum(dim=-1)
+    rhs = (N / M) * (g.conj().to(torch.complex128) * modc.modulate(w)).sum(dim=-1)
+    assert float(((lhs - rhs).abs() / lhs.abs().clamp_min(1e-3)).max()) < 1e-3
