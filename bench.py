@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- GFDM blocks/s on MI355X for BASELINE.json configs[1]: K=64 subcarriers, M=9 timeslots, RRC alpha=0.2,
+overlap=2, batch = 4096 blocks per step, modulate + matched-filter demodulate ("mod+demod").
+
+One STEP = one pass of the hot path over one batch that is already resident in HBM:
+    frames = modulate(symbols)            (HIP kernel 1)
+    out    = demodulate(frames)           (HIP kernel 2, the dominant one: `roofline` describes it)
+Steps rotate through a ring of distinct device buffers (default >= 2 GiB) so that consecutive steps cannot be
+served from the 256 MiB Infinity Cache.  W warm-up steps, then exactly K timed steps bracketed by barrier +
+synchronize on both sides; the time is the MAX over ranks; `value` = all blocks all ranks processed / that time.
+Every rank processes its own 4096-block batches (weak scaling, no data-path collective: GFDM blocks are independent).
+
+Beside the headline the JSON line carries
+  roofline      achieved HBM GB/s of the dominant kernel = algorithmic bytes per launch (16 B/symbol for MF,
+                24 B/symbol with the per-block equaliser vector) / its mean duration measured with
+                HIP events on the launch stream inside the timed region
+  cpu_baseline  the plain-C oracle ("port" of the reference algorithm, oracle/gfdm_oracle.c) timed on this host's cores
+                on a bounded sample of the same workload (rank 0, N=1 only)
+  paths         the same measurement for each receiver variant (MF, ZF, ZF + 2 IC iterations = configs[2], the
+                north-star path) and the modulator, each over its own ring
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gr-gfdm_amd", "python"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+
+CFG = dict(K=64, M=9, L=2, alpha=0.2)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="GFDM blocks per step and per GPU (configs[1]: 4096)")
+    ap.add_argument("--ring-mib", type=int, default=2048, help="total footprint of the buffer ring per path")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-paths", action="store_true", help="skip the per-variant measurements")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of each cpu_baseline leg")
+    return ap.parse_args()
+
+
+class Ring:
+    """Ring of device buffers for one path; slot s holds a full batch of inputs and its output."""
+
+    def __init__(self, nslots, make_inputs, batch, N, device):
+        self.inputs = [make_inputs(s) for s in range(nslots)]
+        self.outs = [torch.empty(batch, N, dtype=torch.complex64, device=device) for _ in range(nslots)]
+        self.n = nslots
+
+
+def raw_launcher(fn, handle, out_t, in_ts, nblocks, stream_ptr):
+    """Pre-marshalled ctypes call (keeps per-launch host cost at ~1-2 us)."""
+    args = [handle, ctypes.c_void_p(out_t.data_ptr())] + [ctypes.c_void_p(t.data_ptr()) if t is not None else None for t in in_ts]
+    args += [ctypes.c_int64(nblocks), ctypes.c_void_p(stream_ptr)]
+
+    def go():
+        rc = fn(*args)
+        if rc != 0:
+            raise RuntimeError("gfdm_hip launch failed: %d" % rc)
+    return go
+
+
+def timed_loop(step_fns, dominant, steps, warmup, world):
+    """Run warmup + `steps` timed steps.  step_fns[i] is a list of launch closures for ring slot i;
+    `dominant` is the index (within a step) of the kernel the roofline describes.
+    Returns (wall seconds of the timed region, mean duration in ms of the dominant kernel from HIP events)."""
+    nslots = len(step_fns)
+    for i in range(warmup):
+        for f in step_fns[i % nslots]:
+            f()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        fns = step_fns[(warmup + i) % nslots]
+        for j, f in enumerate(fns):
+            if j == dominant:
+                ev[i][0].record()
+                f()
+                ev[i][1].record()
+            else:
+                f()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    return wall, kern_ms
+
+
+def cpu_baseline(taps, batch_blocks, seconds):
+    """Time the plain-C oracle (reference algorithm, restated; FFTW/VOLK are not installed) on mod + MF demod.
+    Leg 1: one kernel object, one thread, block by block (how simple_receiver_cc_impl::work drives the reference).
+    Leg 2: T threads, one kernel object each, disjoint block ranges, T = all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    lib = None
+    try:    # rebuild for this host's ISA; fall back to the shipped portable build
+        path = "/tmp/libgfdm_oracle_native_%d.so" % os.getpid()
+        c_oracle.build(cflags=["-O3", "-march=native"], out=path)
+        lib = c_oracle.load(path)
+    except Exception:
+        lib = c_oracle.load()
+    K, M, L = CFG["K"], CFG["M"], CFG["L"]
+    N = K * M
+    rng = np.random.default_rng(0)
+    nb = 2048
+    sym = (((1 - 2 * rng.integers(0, 2, (nb, N))) + 1j * (1 - 2 * rng.integers(0, 2, (nb, N)))) / np.sqrt(2)).astype(np.complex64)
+
+    def run(o, reps):
+        for _ in range(reps):
+            o.demodulate(o.modulate(sym))
+
+    o = c_oracle.COracle(M, K, L, taps, lib=lib)
+    t = time.perf_counter(); run(o, 1); dt = time.perf_counter() - t
+    reps = max(1, int(seconds / max(dt, 1e-3)))
+    t = time.perf_counter(); run(o, reps); single = reps * nb / (time.perf_counter() - t)
+    T = os.cpu_count() or 1
+    objs = [c_oracle.COracle(M, K, L, taps, lib=lib) for _ in range(T)]
+    threads = [threading.Thread(target=run, args=(objs[i], reps)) for i in range(T)]
+    t = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    multi = T * reps * nb / (time.perf_counter() - t)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": multi, "unit": "blocks/s", "cores": T, "kind": "port",
+            "sample": "mod + MF demod of %d x %d QPSK blocks per thread, K=64 M=9 L=2, plain-C oracle (-O3 -march=native), "
+                      "one kernel object per thread" % (reps, nb),
+            "single_thread_value": single, "cpu_model": model}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels have no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL; only barriers/stat reductions
+
+    import gfdm_amd
+    from gfdm_amd import sharding, synth
+    from gfdm_amd.filters import get_frequency_domain_filter
+
+    K, M, L = CFG["K"], CFG["M"], CFG["L"]
+    N, B = K * M, a.batch
+    taps = get_frequency_domain_filter("rrc", CFG["alpha"], M, K, L)
+    mod = gfdm_amd.Modulator(M, K, L, taps, device=local)
+    dem = gfdm_amd.Demodulator(M, K, L, np.conj(taps), device=local)          # rx taps = conj(tx taps)  (matched filter)
+    qpsk = np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) / np.sqrt(2)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, np.conj(taps), np.arange(K), 2, qpsk, device=local)
+    L_ = gfdm_amd.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    buf_bytes = B * N * 8
+
+    def slots(nbuf):
+        return max(2, min(256, (a.ring_mib << 20) // (nbuf * buf_bytes)))
+
+    gblock = lambda s: (rank * 1000003 + s) * B          # distinct global block range per rank and slot
+
+    # ---- headline: mod + MF demod -------------------------------------------------------------------------------
+    ns = slots(3)
+    sym = [synth.qpsk_symbols(gblock(s), B, N, dev) for s in range(ns)]
+    frames = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(ns)]
+    outs = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(ns)]
+    steps_fns = [[raw_launcher(L_.gfdm_hip_modulator_work_device, mod._h, frames[s], [sym[s]], B, stream),
+                  raw_launcher(L_.gfdm_hip_receiver_demodulate_device, dem._h, outs[s], [frames[s], None], B, stream)]
+                 for s in range(ns)]
+    wall, kern_ms = timed_loop(steps_fns, 1, a.steps, a.warmup, world)
+    chk = sharding.output_checksum(outs[(a.warmup + a.steps - 1) % ns])
+    total_blocks, chk, wall_max = sharding.reduce_stats(B * a.steps, chk, wall, dev)
+    value = total_blocks / wall_max
+    achieved = 16.0 * N * B / (kern_ms * 1e-3) / 1e9
+    result = {
+        "metric": "GFDM blocks/s, K=64 M=9 mod+demod (MF), batch 4096 per GPU",
+        "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": wall_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: K=64 subcarriers, M=9 timeslots, RRC alpha=0.2, overlap=2, MF receiver, "
+                               "%d QPSK blocks per step per GPU, step = modulate + demodulate, ring of %d buffer sets" % (B, ns),
+                   "block_size": N, "batch_per_gpu": B, "sharding": "independent blocks per GPU, no data-path collective"},
+        "msym_per_s": value * N / 1e6,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "kernel": dem.kernel_name() + " (demodulate, MF)", "bytes_per_launch": 16 * N * B,
+                     "kernel_ms": kern_ms},
+        "kernels": {"modulate": mod.kernel_name(), "demodulate": dem.kernel_name(), "advanced": adv.kernel_name()},
+        "output_checksum": [float(v) for v in chk],
+    }
+    del sym, frames, outs, steps_fns
+
+    # ---- per-variant measurements (each alone on the stream, own ring) ----------------------------------------------
+    if not a.no_paths:
+        paths = {}
+
+        def measure(name, nbuf, bytes_per_sym, make_fns):
+            n_slots = slots(nbuf)
+            fns, keep = make_fns(n_slots)
+            w, kms = timed_loop(fns, 0, a.steps, a.warmup, world)
+            _, _, wmax = sharding.reduce_stats(0, torch.zeros(3, dtype=torch.float64, device=dev), w, dev)
+            gbps = bytes_per_sym * N * B / (kms * 1e-3) / 1e9
+            paths[name] = {"blocks_per_s": world * B * a.steps / wmax, "msym_per_s": world * B * a.steps / wmax * N / 1e6,
+                           "kernel_ms": kms, "bytes_per_launch": bytes_per_sym * N * B, "achieved_GBps": gbps,
+                           "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "ring_slots": n_slots}
+            del keep
+
+        def rx_inputs(n_slots, with_eq):
+            fr, eq = [], []
+            for s in range(n_slots):
+                x = mod.modulate(synth.qpsk_symbols(gblock(s), B, N, dev))
+                if with_eq:
+                    f = synth.channel_response(gblock(s), B, N, dev)
+                    x = synth.through_channel(x, f)
+                    eq.append(f)
+                fr.append(x)
+            torch.cuda.synchronize()
+            return fr, eq
+
+        def mk_mod(n_slots):
+            i = [synth.qpsk_symbols(gblock(s), B, N, dev) for s in range(n_slots)]
+            o = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(n_slots)]
+            return [[raw_launcher(L_.gfdm_hip_modulator_work_device, mod._h, o[s], [i[s]], B, stream)] for s in range(n_slots)], (i, o)
+
+        def mk_rx(fn, handle, with_eq):
+            def make(n_slots):
+                fr, eq = rx_inputs(n_slots, with_eq)
+                o = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(n_slots)]
+                return [[raw_launcher(fn, handle, o[s], [fr[s], eq[s] if with_eq else None], B, stream)] for s in range(n_slots)], (fr, eq, o)
+            return make
+
+        measure("modulate", 2, 16, mk_mod)
+        measure("demod_mf", 2, 16, mk_rx(L_.gfdm_hip_receiver_demodulate_device, dem._h, False))
+        measure("demod_zf", 3, 24, mk_rx(L_.gfdm_hip_receiver_demodulate_device, dem._h, True))
+        measure("demod_mf_ic2", 2, 16, mk_rx(L_.gfdm_hip_advanced_receiver_work_device, adv._h, False))
+        measure("demod_zf_ic2", 3, 24, mk_rx(L_.gfdm_hip_advanced_receiver_work_device, adv._h, True))
+        result["paths"] = paths
+        result["north_star"] = {"path": "demod_zf_ic2 (BASELINE configs[2]: ZF demod + 2 IC iterations)",
+                                "frac_of_hbm_peak": paths["demod_zf_ic2"]["frac_of_hbm_peak"], "target": 0.40}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(taps, B, a.cpu_seconds)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -44,6 +45,8 @@ struct Plan {
     cf* stage[3] = { nullptr, nullptr, nullptr };
     size_t stage_elems[3] = { 0, 0, 0 };
     std::string kernel_name;
+    const cf* d_twT = nullptr;       // [M][K] twiddles of the fast family
+    bool fast = false;
 
     ~Plan()
     {
@@ -119,12 +122,21 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
         }
 
     std::vector<cf> tables;
-    tables.reserve((size_t)ntaps + M + M + K + N);
+    tables.reserve((size_t)ntaps + M + M + K + 2 * (size_t)N);
     tables.insert(tables.end(), pl.h_taps.begin(), pl.h_taps.end());
     tables.insert(tables.end(), pl.h_ictaps.begin(), pl.h_ictaps.end());
     unit_roots(tables, M);
     unit_roots(tables, K);
     unit_roots(tables, N);
+    const size_t twT_off = tables.size();
+    {
+        const double two_pi = 6.283185307179586476925286766559;
+        for (int m = 0; m < M; ++m)
+            for (int q = 0; q < K; ++q) {
+                const double a = -two_pi * (double)(((int64_t)q * m) % N) / (double)N;
+                tables.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
+            }
+    }
 
     DeviceGuard guard(device);
     if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
@@ -141,7 +153,9 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     dp.wM = dp.ictaps + M;
     dp.wK = dp.wM + M;
     dp.wN = dp.wK + K;
-    pl.kernel_name = "generic_lds";
+    pl.d_twT = pl.d_tables + twT_off;
+    pl.fast = gfdm::fast_supports(M, K, L) && getenv("GFDM_HIP_FORCE_GENERIC") == nullptr;
+    pl.kernel_name = pl.fast ? "fast_wave_tile" : "generic_lds";
     return GFDM_HIP_OK;
 }
 
@@ -188,6 +202,19 @@ int run_device(Plan& pl, void* out, const void* in0, int64_t nblocks, Launch lau
     hipError_t e = launch();
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return GFDM_HIP_OK;
+}
+
+hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks,
+                            hipStream_t s)
+{
+    if (pl.fast) return gfdm::launch_fast_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    return gfdm::launch_generic_receive(pl.dp, ic, mode, out, in, f_eq, nblocks, s);
+}
+
+hipError_t mod_launch(Plan& pl, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
+{
+    if (pl.fast) return gfdm::launch_fast_modulate(pl.dp, pl.d_twT, out, in, nblocks, s);
+    return gfdm::launch_generic_modulate(pl.dp, out, in, nblocks, s);
 }
 
 const gfdm::IcParams kNoIc = { 0, 0, 0, 0, nullptr, nullptr, 0, nullptr };
@@ -270,7 +297,7 @@ int gfdm_hip_modulator_work_device(gfdm_hip_modulator* m, void* out, const void*
 {
     if (!m) return fail(GFDM_HIP_EINVAL, "NULL handle");
     return run_device(m->plan, out, in, nblocks, [&]() {
-        return gfdm::launch_generic_modulate(m->plan.dp, (cf*)out, (const cf*)in, nblocks, (hipStream_t)stream);
+        return mod_launch(m->plan, (cf*)out, (const cf*)in, nblocks, (hipStream_t)stream);
     });
 }
 
@@ -278,7 +305,7 @@ int gfdm_hip_modulator_work_host(gfdm_hip_modulator* m, float* out, const float*
 {
     if (!m) return fail(GFDM_HIP_EINVAL, "NULL handle");
     return run_host(m->plan, out, in, nullptr, nblocks, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
-        return gfdm::launch_generic_modulate(m->plan.dp, o, i, nblocks, s);
+        return mod_launch(m->plan, o, i, nblocks, s);
     });
 }
 
@@ -318,12 +345,6 @@ int gfdm_hip_receiver_ic_filter_taps(const gfdm_hip_receiver* r, float* out)
 }
 
 const char* gfdm_hip_receiver_kernel_name(const gfdm_hip_receiver* r) { return r ? r->plan.kernel_name.c_str() : ""; }
-
-static hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks,
-                            hipStream_t s)
-{
-    return gfdm::launch_generic_receive(pl.dp, ic, mode, out, in, f_eq, nblocks, s);
-}
 
 int gfdm_hip_receiver_demodulate_device(gfdm_hip_receiver* r, void* out, const void* in, const void* f_eq, int64_t nblocks, void* stream)
 {

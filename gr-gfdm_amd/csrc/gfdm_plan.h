@@ -50,4 +50,11 @@ hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int6
 hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, const cf* fd, int64_t nblocks, hipStream_t s);
 bool generic_supports(int N, bool ic);
 
+// ---- fast family (gfdm_fast.hip): register/LDS tiles, one wavefront per workgroup, compile-time shapes ----
+// twT: [M][K] table, twT[m*K + q] = exp(-2 pi j q m / N)
+bool fast_supports(int M, int K, int L);
+hipError_t launch_fast_modulate(const DevicePlan& p, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+hipError_t launch_fast_receive(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in, const cf* f_eq,
+                               int64_t nblocks, hipStream_t s);
+
 }  // namespace gfdm
