@@ -46,7 +46,7 @@ struct Plan {
     size_t stage_elems[3] = { 0, 0, 0 };
     std::string kernel_name;
     const cf* d_twT = nullptr;       // [M][K] twiddles of the fast family
-    bool fast = false;
+    int family = gfdm::FAMILY_GENERIC;
 
     ~Plan()
     {
@@ -122,9 +122,10 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
         }
 
     std::vector<cf> tables;
-    tables.reserve((size_t)ntaps + M + M + K + 2 * (size_t)N);
+    tables.reserve((size_t)ntaps + 3 * M + K + 2 * (size_t)N);
     tables.insert(tables.end(), pl.h_taps.begin(), pl.h_taps.end());
     tables.insert(tables.end(), pl.h_ictaps.begin(), pl.h_ictaps.end());
+    for (int m = 0; m < M; ++m) tables.push_back(make_float2(pl.h_ictaps[m].x / (float)M, pl.h_ictaps[m].y / (float)M));
     unit_roots(tables, M);
     unit_roots(tables, K);
     unit_roots(tables, N);
@@ -150,12 +151,20 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     dp.part_len = (M * L / 2 < M) ? (M * L / 2) : M;
     dp.taps = pl.d_tables;
     dp.ictaps = dp.taps + ntaps;
-    dp.wM = dp.ictaps + M;
+    dp.ictaps_m = dp.ictaps + M;
+    dp.wM = dp.ictaps_m + M;
     dp.wK = dp.wM + M;
     dp.wN = dp.wK + K;
     pl.d_twT = pl.d_tables + twT_off;
-    pl.fast = gfdm::fast_supports(M, K, L) && getenv("GFDM_HIP_FORCE_GENERIC") == nullptr;
-    pl.kernel_name = pl.fast ? "fast_wave_tile" : "generic_lds";
+    // kernel family: row-lane where instantiated, then the 4-rows-per-lane family, else the generic LDS family.
+    // GFDM_HIP_FAMILY=generic|fast|rowlane overrides the choice (experiments, A/B timing).
+    pl.family = gfdm::rowlane_supports(M, K, L) ? gfdm::FAMILY_ROWLANE : gfdm::fast_supports(M, K, L) ? gfdm::FAMILY_FAST : gfdm::FAMILY_GENERIC;
+    if (const char* want = getenv("GFDM_HIP_FAMILY")) {
+        if (!strcmp(want, "generic")) pl.family = gfdm::FAMILY_GENERIC;
+        else if (!strcmp(want, "fast") && gfdm::fast_supports(M, K, L)) pl.family = gfdm::FAMILY_FAST;
+        else if (!strcmp(want, "rowlane") && gfdm::rowlane_supports(M, K, L)) pl.family = gfdm::FAMILY_ROWLANE;
+    }
+    pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : pl.family == gfdm::FAMILY_FAST ? "fast_wave_tile" : "generic_lds";
     return GFDM_HIP_OK;
 }
 
@@ -207,13 +216,15 @@ int run_device(Plan& pl, void* out, const void* in0, int64_t nblocks, Launch lau
 hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks,
                             hipStream_t s)
 {
-    if (pl.fast) return gfdm::launch_fast_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    if (pl.family == gfdm::FAMILY_FAST) return gfdm::launch_fast_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
     return gfdm::launch_generic_receive(pl.dp, ic, mode, out, in, f_eq, nblocks, s);
 }
 
 hipError_t mod_launch(Plan& pl, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
-    if (pl.fast) return gfdm::launch_fast_modulate(pl.dp, pl.d_twT, out, in, nblocks, s);
+    if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_modulate(pl.dp, pl.d_twT, out, in, nblocks, s);
+    if (pl.family == gfdm::FAMILY_FAST) return gfdm::launch_fast_modulate(pl.dp, pl.d_twT, out, in, nblocks, s);
     return gfdm::launch_generic_modulate(pl.dp, out, in, nblocks, s);
 }
 
@@ -456,7 +467,10 @@ int gfdm_hip_advanced_receiver_create(gfdm_hip_advanced_receiver** out, int time
     std::vector<unsigned char> blob(pts_bytes + smap_bytes + act_bytes, 0);
     memcpy(blob.data(), pts, pts_bytes);
     if (n_subcarrier_map > 0) memcpy(blob.data() + pts_bytes, subcarrier_map, (size_t)n_subcarrier_map * sizeof(int));
-    for (int i = 0; i < n_subcarrier_map; ++i) blob[pts_bytes + smap_bytes + subcarrier_map[i]] = 1;
+    for (int i = 0; i < n_subcarrier_map; ++i) {            // multiplicity of each subcarrier in the map (saturating)
+        unsigned char& c = blob[pts_bytes + smap_bytes + subcarrier_map[i]];
+        if (c < 255) ++c;
+    }
     {
         DeviceGuard guard(device);
         hipError_t e = hipMalloc(&a->d_ic, blob.size());

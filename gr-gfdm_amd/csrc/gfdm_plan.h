@@ -18,6 +18,7 @@ struct DevicePlan {
     int part_len;   // min(M*L/2, M): bins of each tap part the modulator accumulates (modulator_kernel_cc.cc:101)
     const cf* taps;     // [L*M] normalised filter taps
     const cf* ictaps;   // [M]   ic[m] = t[m] * t[(L-1)M + m]
+    const cf* ictaps_m; // [M]   ic[m] / M (IC taps with the inverse-DFT scale folded in)
     const cf* wM;       // [M]   exp(-2 pi j p / M)
     const cf* wK;       // [K]   exp(-2 pi j q / K)
     const cf* wN;       // [N]   exp(-2 pi j r / N)
@@ -30,7 +31,7 @@ struct IcParams {
     int decision;              // gfdm_hip_decision (never AUTO on the device)
     int npoints;
     const cf* points;          // [npoints]
-    const unsigned char* active;   // [K] 1 when the subcarrier is in subcarrier_map
+    const unsigned char* active;   // [K] how often the subcarrier occurs in subcarrier_map (0 = inactive)
     int n_active;              // subcarrier_map.size() (duplicates counted, as the reference does)
     const int* smap;           // [n_active] the subcarrier_map itself (order matters for the phase sum)
 };
@@ -56,5 +57,13 @@ bool fast_supports(int M, int K, int L);
 hipError_t launch_fast_modulate(const DevicePlan& p, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
 hipError_t launch_fast_receive(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in, const cf* f_eq,
                                int64_t nblocks, hipStream_t s);
+
+// ---- row-lane family (gfdm_rowlane.hip): one lane per subcarrier row, LDS ping-pong radix-4 passes ----
+bool rowlane_supports(int M, int K, int L);
+hipError_t launch_rowlane_modulate(const DevicePlan& p, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in,
+                                  const cf* f_eq, int64_t nblocks, hipStream_t s);
+
+enum KernelFamily { FAMILY_GENERIC = 0, FAMILY_FAST = 1, FAMILY_ROWLANE = 2 };
 
 }  // namespace gfdm

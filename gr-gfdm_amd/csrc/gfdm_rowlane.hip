@@ -1,0 +1,339 @@
+// "Row-lane" HIP kernel family for gfx950: one lane per subcarrier row, one GFDM block per K lanes.
+//
+// Why a second family: the benchmark batch (4096 blocks of K = 64, M = 9) is only 2.4 M symbols.  Spread over
+// 256 CUs x 4 SIMDs that is four blocks per SIMD, so a layout that packs several blocks into one wavefront
+// (gfdm_fast.hip: 4 rows per lane) leaves one wavefront per SIMD and the launch runs at the latency of a single
+// wave.  Here a block occupies K lanes (a whole wavefront at K = 64; two at K = 128; four at K = 256): 4096 blocks
+// become 4096 waves = 16 per CU, enough to overlap HBM latency, LDS exchanges and VALU work across waves.
+//
+// Decomposition (n = K p + q, f = M j + m):  X[M j + m] = sum_q W_K^{q j} W_N^{q m} (sum_p x[K p + q] W_M^{p m})
+//   phase A  lane q: loads x[K p + q] (a 512-byte contiguous segment per wave instruction), M-point DFT codelet
+//            (gfdm_dft.h), twiddle W_N^{q m} from a [M][K] table (coalesced), row -> LDS tile [q][m]
+//   phase B  K-point FFT over q for all M columns: radix-4 Stockham passes between two LDS tiles (ping-pong,
+//            one barrier per pass).  Lane (tq, cg) owns the four rows tq + (K/4) r of column group cg
+//            (ceil(M/4) columns): every pass reads exactly those rows, so addresses are base + immediates.
+//   phase C  one-tap equaliser X[f] /= f_eq[f] in linear order (f_eq prefetched at kernel start, coalesced)
+//   phase D  lane k: L-tap filter + fold over rows k - L/2 .. k + L/2 - 1 (+wrap), M-point inverse DFT
+//   IC       decided symbols -> tile, neighbours k-1 / k+1 from the tile, DFT, subtract, inverse DFT (per round)
+//   output   row -> tile, linear read, coalesced store
+// HBM traffic: x (+ f_eq) in, out out; nothing else leaves the CU.  The modulator is the transposed flow.
+//
+// Algorithm restated from gr-gfdm: lib/modulator_kernel_cc.cc:98-141, lib/receiver_kernel_cc.cc:165-334,
+// lib/advanced_receiver_kernel_cc.cc:56-123.
+#include "gfdm_dft.h"
+#include "gfdm_plan.h"
+
+#include <cstdlib>
+
+namespace gfdm {
+namespace {
+
+using namespace dft;
+
+template <int K> struct RowShape {
+    static constexpr int log2K = (K == 4) ? 2 : (K == 8) ? 3 : (K == 16) ? 4 : (K == 32) ? 5 : (K == 64) ? 6 : (K == 128) ? 7 : (K == 256) ? 8 : (K == 512) ? 9 : -1;
+    static_assert(log2K > 0, "row-lane family supports K = 4 .. 512, power of two");
+    static constexpr int NP4 = log2K / 2;
+    static constexpr bool HAS2 = (log2K & 1) != 0;
+    static constexpr int WG = (K >= 64) ? K : 64;          // threads per workgroup
+    static constexpr int BPW = WG / K;                     // blocks per workgroup
+    static constexpr int RG = K / 4;                       // row groups of the FFT passes
+};
+
+constexpr int pow4(int s) { return 1 << (2 * s); }
+
+// LDS tile: [row][M] complex, rows contiguous (M odd => conflict-free row access); tiles of one block are TS apart
+template <int K, int M> struct RowTile {
+    static constexpr int N = K * M;
+    static constexpr int TS = N + ((RowShape<K>::BPW > 1) ? 16 : 0);
+};
+
+// Radix-4 (and trailing radix-2) Stockham passes over the subcarrier axis, IN PLACE in one LDS tile: every lane first
+// pulls its 4 x CMAX inputs into registers, a barrier separates the reads from the (autosort-permuted) writes.
+// One tile instead of a ping-pong pair halves the LDS footprint, i.e. doubles the resident waves per CU.
+template <int K, int M, bool INV>
+__device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const cf* __restrict__ wK)
+{
+    using S = RowShape<K>;
+    constexpr int RG = S::RG, CMAX = (M + 3) / 4;
+    const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+    static_for<0, S::NP4>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int str = pow4(s), len = K / str, ms = len / 4;
+        const int j = tq & (str - 1), qq = tq / str;
+        cf w1, w2, w3;
+        if constexpr (ms > 1) {
+            w1 = wK[(qq * str) & (K - 1)];
+            w2 = wK[(qq * 2 * str) & (K - 1)];
+            w3 = wK[(qq * 3 * str) & (K - 1)];
+        }
+        const cf* rb = tile + tq * M + c0;
+        cf* wb = tile + (j + 4 * str * qq) * M + c0;
+        cf x[CMAX][4];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) { x[c][0] = rb[c]; x[c][1] = rb[RG * M + c]; x[c][2] = rb[2 * RG * M + c]; x[c][3] = rb[3 * RG * M + c]; }
+        });
+        if constexpr (ms > 1) __syncthreads();            // last pass writes the rows it read: no hazard, no barrier
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                Dft<4, INV>::run(x[c]);
+                if constexpr (ms > 1) {
+                    x[c][1] = cmul_dir<INV>(x[c][1], w1);
+                    x[c][2] = cmul_dir<INV>(x[c][2], w2);
+                    x[c][3] = cmul_dir<INV>(x[c][3], w3);
+                }
+                wb[c] = x[c][0]; wb[str * M + c] = x[c][1]; wb[2 * str * M + c] = x[c][2]; wb[3 * str * M + c] = x[c][3];
+            }
+        });
+        __syncthreads();
+    });
+    if constexpr (S::HAS2) {      // len 2, stride K/2: pairs (tq, tq + K/2), (tq + K/4, tq + 3K/4); each lane owns its elements
+        cf* b = tile + tq * M + c0;
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                const cf a0 = b[c], a1 = b[RG * M + c], a2 = b[2 * RG * M + c], a3 = b[3 * RG * M + c];
+                b[c] = a0 + a2; b[2 * RG * M + c] = a0 - a2; b[RG * M + c] = a1 + a3; b[3 * RG * M + c] = a1 - a3;
+            }
+        });
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ cf decide_point(cf x, const IcParams& ic)
+{
+    if (ic.decision == 1) {
+        const float s = 0.70710678118654752f;
+        return mk(x.x > 0.f ? s : -s, x.y > 0.f ? s : -s);
+    }
+    int idx = 0;
+    if (ic.decision == 2) {
+        idx = (x.x > 0.f);
+    } else {
+        float best = INFINITY;
+        for (int i = 0; i < ic.npoints; ++i) {
+            const cf pt = ic.points[i];
+            const float dr = x.x - pt.x, di = x.y - pt.y, d = dr * dr + di * di;
+            if (d < best) { best = d; idx = i; }
+        }
+    }
+    return ic.points[idx];
+}
+
+// =====================================================================================================================
+template <int K, int M, int L, int MODE, bool EQ>
+__global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, IcParams ic, const cf* __restrict__ twT,
+                                                                cf* __restrict__ out, const cf* __restrict__ in,
+                                                                const cf* __restrict__ f_eq, int64_t nblocks)
+{
+    using S = RowShape<K>;
+    using T = RowTile<K, M>;
+    constexpr int N = K * M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int g = threadIdx.x / K, q = threadIdx.x - g * K;            // q doubles as row index k in phase D
+    const int64_t blk = (int64_t)blockIdx.x * S::BPW + g;
+    const bool valid = blk < nblocks;
+    const int64_t base = (valid ? blk : 0) * N;
+    cf* X = reinterpret_cast<cf*>(smem) + g * T::TS;                   // the block's single LDS tile, [row][M]
+
+    // ---- phase A: timeslot DFT of row q, twiddle W_N^{q m}
+    cf v[M];
+    static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = in[base + K * pp + q]; });
+    cf heq[EQ ? M : 1];
+    if constexpr (EQ) static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; heq[i] = f_eq[base + q + K * i]; });
+    dft_inplace<M, false>(v);
+    X[q * M] = v[0];
+    static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = cmul(v[m], twT[m * K + q]); });
+    __syncthreads();
+
+    // ---- phase B: subcarrier FFT, in place
+    lds_subcarrier_fft<K, M, false>(X, q, p.wK);
+
+    // ---- phase C: X[f] / f_eq[f] in linear order (a conj(b) / |b|^2, reciprocal by v_rcp_f32)              rx:315-316
+    if constexpr (EQ) {
+        static_for<0, M>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const cf a = X[q + K * i], b = heq[i];
+            const float inv = __builtin_amdgcn_rcpf(b.x * b.x + b.y * b.y);
+            X[q + K * i] = mk((a.x * b.x + a.y * b.y) * inv, (a.y * b.x - a.x * b.y) * inv);
+        });
+        __syncthreads();
+    }
+
+    // ---- phase D: S[k][m] = sum_i taps[((i + L/2) % L) M + m] X[(k + i - L/2) mod K][m]                      rx:165-192
+    cf s[M];
+    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = mk(0.f, 0.f); });
+    static_for<0, L>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const cf* rb = X + ((q + i - L / 2 + K) & (K - 1)) * M;
+        static_for<0, M>([&](auto mi) {
+            constexpr int m = decltype(mi)::value;
+            s[m] = cfma(p.taps[((i + L / 2) % L) * M + m], rb[m], s[m]);
+        });
+    });
+    constexpr float invM = 1.0f / (float)M;
+    cf d[M];
+    if constexpr (MODE != RX_FD) {
+        // from here on S only feeds inverse DFTs that are scaled by 1/M: fold the scale into S (and into the IC taps)
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = scale(s[m], invM); d[m] = s[m]; });
+        dft_inplace<M, true>(d);                                                                         // rx:211-225
+    }
+    __syncthreads();                                      // every lane has read its neighbour rows: the tile is free
+
+    if constexpr (MODE == RX_IC) {
+        const int wgt = ic.active[q];                     // multiplicity of subcarrier k in subcarrier_map (0 = inactive)
+        float* red = reinterpret_cast<float*>(reinterpret_cast<cf*>(smem) + S::BPW * T::TS);
+        for (int it = 0; it < ic.ic_iter; ++it) {                                                        // adv:56-76
+            const bool pc = (ic.do_phase_compensation > 0) && (it == 0);
+            float acc = 0.f;
+            static_for<0, M>([&](auto mi) {                                                              // adv:109-123
+                constexpr int m = decltype(mi)::value;
+                const cf dec = (wgt > 0) ? decide_point(d[m], ic) : mk(0.f, 0.f);
+                if (pc && wgt > 0) acc += (float)wgt * (atan2f(dec.y, dec.x) - atan2f(d[m].y, d[m].x));
+                X[q * M + m] = dec;
+            });
+            if (pc) {                                                                                    // adv:59-71, 78-91
+                for (int off = 1; off < 64 && off < K; off <<= 1) acc += __shfl_xor(acc, off, 64);
+                if constexpr (K > 64) {
+                    if ((q & 63) == 0) red[q >> 6] = acc;
+                    __syncthreads();
+                    acc = 0.f;
+                    static_for<0, K / 64>([&](auto wi) { acc += red[decltype(wi)::value]; });
+                }
+                const float phi = acc / (float)(ic.n_active * M);
+                float sn, cs;
+                sincosf(phi, &sn, &cs);
+                const cf rot = mk(cs, sn);
+                static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = cmul(s[m], rot); });
+            }
+            __syncthreads();
+            const cf* below = X + ((q - 1 + K) & (K - 1)) * M;                                            // rx:274-299
+            const cf* above = X + ((q + 1) & (K - 1)) * M;
+            cf nb[M];
+            static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; nb[m] = below[m] + above[m]; });
+            dft_inplace<M, false>(nb);
+            static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d[m] = s[m] - cmul(p.ictaps_m[m], nb[m]); });
+            dft_inplace<M, true>(d);
+            __syncthreads();                              // all neighbour reads done before the tile is rewritten
+        }
+    }
+
+    // ---- output: row -> tile, linear read, coalesced store
+    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = (MODE == RX_FD) ? s[m] : d[m]; });
+    __syncthreads();
+    if (valid) {
+        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; out[base + q + K * i] = X[q + K * i]; });
+    }
+}
+
+// =====================================================================================================================
+template <int K, int M, int L>
+__global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, const cf* __restrict__ twT, cf* __restrict__ out,
+                                                                 const cf* __restrict__ in, int64_t nblocks)
+{
+    using S = RowShape<K>;
+    using T = RowTile<K, M>;
+    constexpr int N = K * M;
+    constexpr int PART = (M * L / 2 < M) ? (M * L / 2) : M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int g = threadIdx.x / K, q = threadIdx.x - g * K;
+    const int64_t blk = (int64_t)blockIdx.x * S::BPW + g;
+    const bool valid = blk < nblocks;
+    const int64_t base = (valid ? blk : 0) * N;
+    cf* X = reinterpret_cast<cf*>(smem) + g * T::TS;
+
+    // symbols [k][p], copied linearly (coalesced) into the tile; lane k then owns row k
+    static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; X[q + K * i] = in[base + q + K * i]; });
+    __syncthreads();
+    cf v[M];
+    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = X[q * M + m]; });
+    dft_inplace<M, false>(v);                                                                          // mod:109-110
+    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = v[m]; });    // own row: no hazard
+    __syncthreads();
+    // gather form of filter + overlap-add: Y[j][m] = sum_i D[(j - i + L/2) mod K][m] taps[((i + L/2) % L) M + m]   mod:116-132
+    constexpr float invN = 1.0f / (float)N;
+    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = mk(0.f, 0.f); });
+    static_for<0, L>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const cf* rb = X + ((q - i + L / 2 + K) & (K - 1)) * M;
+        static_for<0, PART>([&](auto mi) {
+            constexpr int m = decltype(mi)::value;
+            v[m] = cfma(rb[m], p.taps[((i + L / 2) % L) * M + m], v[m]);
+        });
+    });
+    __syncthreads();                                      // neighbour rows read by everyone before they are overwritten
+    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = scale(v[m], invN); });
+    __syncthreads();
+    lds_subcarrier_fft<K, M, true>(X, q, p.wK);                                                         // inverse over j
+    v[0] = X[q * M];
+    static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = cmulc(X[q * M + m], twT[m * K + q]); });
+    dft_inplace<M, true>(v);                                                                           // mod:137-140
+    if (valid) {
+        static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; out[base + K * pp + q] = v[pp]; });
+    }
+}
+
+template <int K, int M> constexpr size_t row_lds_bytes() { return (size_t)RowShape<K>::BPW * RowTile<K, M>::TS * sizeof(cf) + 64; }
+
+template <int K, int M, int L>
+hipError_t launch_rx(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in, const cf* f_eq,
+                     int64_t nblocks, hipStream_t st)
+{
+    constexpr size_t lds = row_lds_bytes<K, M>();
+    static_assert(lds <= 64 * 1024, "row-lane tile exceeds the default dynamic LDS limit");
+    const dim3 grid((unsigned)((nblocks + RowShape<K>::BPW - 1) / RowShape<K>::BPW)), block(RowShape<K>::WG);
+#define GFDM_RX(MODE_, EQ_) hipLaunchKernelGGL((k_row_receive<K, M, L, MODE_, EQ_>), grid, block, lds, st, p, ic, twT, out, in, f_eq, nblocks)
+    if (mode == RX_FD) { if (f_eq) GFDM_RX(RX_FD, true); else GFDM_RX(RX_FD, false); }
+    else if (mode == RX_DEMOD || ic.ic_iter <= 0) { if (f_eq) GFDM_RX(RX_DEMOD, true); else GFDM_RX(RX_DEMOD, false); }
+    else { if (f_eq) GFDM_RX(RX_IC, true); else GFDM_RX(RX_IC, false); }
+#undef GFDM_RX
+    return hipGetLastError();
+}
+
+template <int K, int M, int L>
+hipError_t launch_mod(const DevicePlan& p, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t st)
+{
+    constexpr size_t lds = row_lds_bytes<K, M>();
+    const dim3 grid((unsigned)((nblocks + RowShape<K>::BPW - 1) / RowShape<K>::BPW)), block(RowShape<K>::WG);
+    hipLaunchKernelGGL((k_row_modulate<K, M, L>), grid, block, lds, st, p, twT, out, in, nblocks);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+#define GFDM_ROW_SHAPES(X) \
+    X(64, 9, 2)            \
+    X(32, 5, 2)            \
+    X(32, 9, 2)            \
+    X(128, 15, 4)
+
+bool rowlane_supports(int M, int K, int L)
+{
+#define X(K_, M_, L_) if (K == K_ && M == M_ && L == L_) return true;
+    GFDM_ROW_SHAPES(X)
+#undef X
+    return false;
+}
+
+hipError_t launch_rowlane_modulate(const DevicePlan& p, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return hipSuccess;
+#define X(K_, M_, L_) if (p.K == K_ && p.M == M_ && p.L == L_) return launch_mod<K_, M_, L_>(p, twT, out, in, nblocks, s);
+    GFDM_ROW_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in,
+                                  const cf* f_eq, int64_t nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return hipSuccess;
+#define X(K_, M_, L_) if (p.K == K_ && p.M == M_ && p.L == L_) return launch_rx<K_, M_, L_>(p, ic, twT, mode, out, in, f_eq, nblocks, s);
+    GFDM_ROW_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace gfdm
