@@ -13,7 +13,8 @@ Every rank processes its own 4096-block batches (weak scaling, no data-path coll
 Beside the headline the JSON line carries
   roofline      achieved HBM GB/s of the dominant kernel = algorithmic bytes per launch (16 B/symbol for MF,
                 24 B/symbol with the per-block equaliser vector) / its mean duration measured with
-                HIP events on the launch stream inside the timed region
+                HIP events on the launch stream around every launch of the timed region (this includes ~2-3 us of
+                dispatch latency per launch that rocprofv3's kernel trace does not count: profiles/README.md)
   cpu_baseline  the plain-C oracle ("port" of the reference algorithm, oracle/gfdm_oracle.c) timed on this host's cores
                 on a bounded sample of the same workload (rank 0, N=1 only)
   paths         the same measurement for each receiver variant (MF, ZF, ZF + 2 IC iterations = configs[2], the
@@ -90,7 +91,7 @@ def timed_loop(step_fns, dominant, steps, warmup, world):
     for i in range(steps):
         fns = step_fns[(warmup + i) % nslots]
         for j, f in enumerate(fns):
-            if j == dominant:
+            if j == dominant:         # HIP events on the launch stream (torch's current stream) around every launch
                 ev[i][0].record()
                 f()
                 ev[i][1].record()
@@ -108,10 +109,10 @@ def timed_loop(step_fns, dominant, steps, warmup, world):
 def cpu_baseline(taps, batch_blocks, seconds):
     """Time the plain-C oracle (reference algorithm, restated; FFTW/VOLK are not installed) on mod + MF demod.
     Leg 1: one kernel object, one thread, block by block (how simple_receiver_cc_impl::work drives the reference).
-    Leg 2: T threads, one kernel object each, disjoint block ranges, T = all host cores."""
+    Leg 2: T threads, one kernel object each, disjoint block ranges, T = the cores this process may run on.
+    Both legs are time-bounded (`seconds` each) so the default bench run stays within minutes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
-    lib = None
     try:    # rebuild for this host's ISA; fall back to the shipped portable build
         path = "/tmp/libgfdm_oracle_native_%d.so" % os.getpid()
         c_oracle.build(cflags=["-O3", "-march=native"], out=path)
@@ -121,26 +122,37 @@ def cpu_baseline(taps, batch_blocks, seconds):
     K, M, L = CFG["K"], CFG["M"], CFG["L"]
     N = K * M
     rng = np.random.default_rng(0)
-    nb = 2048
+    nb = 1024
     sym = (((1 - 2 * rng.integers(0, 2, (nb, N))) + 1j * (1 - 2 * rng.integers(0, 2, (nb, N)))) / np.sqrt(2)).astype(np.complex64)
 
-    def run(o, reps):
-        for _ in range(reps):
+    def run(o, deadline, counter, idx):
+        n = 0
+        while True:
             o.demodulate(o.modulate(sym))
+            n += nb
+            if time.perf_counter() >= deadline:
+                break
+        counter[idx] = n
 
-    o = c_oracle.COracle(M, K, L, taps, lib=lib)
-    t = time.perf_counter(); run(o, 1); dt = time.perf_counter() - t
-    reps = max(1, int(seconds / max(dt, 1e-3)))
-    t = time.perf_counter(); run(o, reps); single = reps * nb / (time.perf_counter() - t)
-    T = os.cpu_count() or 1
-    objs = [c_oracle.COracle(M, K, L, taps, lib=lib) for _ in range(T)]
-    threads = [threading.Thread(target=run, args=(objs[i], reps)) for i in range(T)]
-    t = time.perf_counter()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    multi = T * reps * nb / (time.perf_counter() - t)
+    def leg(nthreads):
+        objs = [c_oracle.COracle(M, K, L, taps, lib=lib) for _ in range(nthreads)]
+        counter = [0] * nthreads
+        t0 = time.perf_counter()
+        deadline = t0 + seconds
+        threads = [threading.Thread(target=run, args=(objs[i], deadline, counter, i)) for i in range(nthreads)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        return sum(counter) / (time.perf_counter() - t0), sum(counter)
+
+    single, n1 = leg(1)
+    try:
+        T = len(os.sched_getaffinity(0))
+    except AttributeError:
+        T = os.cpu_count() or 1
+    T = max(1, min(T, 64))
+    multi, nT = leg(T)
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -150,9 +162,9 @@ def cpu_baseline(taps, batch_blocks, seconds):
     except OSError:
         pass
     return {"value": multi, "unit": "blocks/s", "cores": T, "kind": "port",
-            "sample": "mod + MF demod of %d x %d QPSK blocks per thread, K=64 M=9 L=2, plain-C oracle (-O3 -march=native), "
-                      "one kernel object per thread" % (reps, nb),
-            "single_thread_value": single, "cpu_model": model}
+            "sample": "mod + MF demod of %d QPSK blocks (K=64 M=9 L=2) in %.0f s on %d threads, one plain-C oracle kernel object "
+                      "per thread (-O3 -march=native); single thread: %d blocks in %.0f s" % (nT, seconds, T, n1, seconds),
+            "single_thread_value": single, "cpu_model": model, "host_logical_cpus": os.cpu_count()}
 
 
 def main():

@@ -1,0 +1,80 @@
+"""Brute-force LDS bank-conflict model for the row-lane kernel (K=64, M=9), gfx950 ds_read_b64 / ds_write_b64 rules:
+reads: 2 groups of 32 lanes, bank = (addr/4) % 64; writes: 4 groups of 16 lanes, bank = (addr/4) % 32.
+cost of a group = max over banks of #distinct dword addresses on that bank (each b64 touches 2 consecutive dwords)."""
+import itertools, sys
+K, M = 64, 9
+def cost(addrs, is_read):
+    # addrs: list of 64 complex-element addresses (None = inactive lane)
+    gs, nb = (32, 64) if is_read else (16, 32)
+    tot = 0
+    for g0 in range(0, 64, gs):
+        banks = {}
+        for l in range(g0, g0 + gs):
+            a = addrs[l]
+            if a is None: continue
+            for dw in (2 * a, 2 * a + 1):
+                banks.setdefault(dw % nb, set()).add(dw)
+        tot += max((len(v) for v in banks.values()), default=0)
+    return tot
+def patterns(addr):
+    P = []   # (name, is_read, list-of-lane-address-lists)
+    P.append(("A_w", False, [[addr(q, m) for q in range(64)] for m in range(M)]))
+    for s in range(3):
+        st = 4 ** s
+        rd, wr = [], []
+        for c in range(3):
+            for r in range(4):
+                rd.append([addr((l % 16) + 16 * r, 3 * (l // 16) + c) if l < 48 else None for l in range(64)])
+            for u in range(4):
+                wr.append([addr(((l % 16) % st) + 4 * st * ((l % 16) // st) + st * u, 3 * (l // 16) + c) if l < 48 else None for l in range(64)])
+        P.append(("F%d_r" % s, True, rd)); P.append(("F%d_w" % s, False, wr))
+    lin = lambda e: addr(e // M, e % M)
+    P.append(("C_r", True, [[lin(q + 64 * i) for q in range(64)] for i in range(M)]))
+    P.append(("C_w", False, [[lin(q + 64 * i) for q in range(64)] for i in range(M)]))
+    P.append(("D_r", True, [[addr((q + d) % 64, m) for q in range(64)] for d in (-1, 0) for m in range(M)]))
+    P.append(("IC_w", False, [[addr(q, m) for q in range(64)] for m in range(M)] * 2))
+    P.append(("IC_r", True, [[addr((q + d) % 64, m) for q in range(64)] for d in (-1, 1) for m in range(M)] * 2))
+    P.append(("O_w", False, [[addr(q, m) for q in range(64)] for m in range(M)]))
+    P.append(("O_r", True, [[lin(q + 64 * i) for q in range(64)] for i in range(M)]))
+    return P
+def evaluate(addr, verbose=False):
+    tot = 0; ideal = 0
+    for name, rd, lst in patterns(addr):
+        c = sum(cost(a, rd) for a in lst); i = len(lst) * (2 if rd else 4)
+        tot += c; ideal += i
+        if verbose: print("  %-5s %4d (ideal %3d)" % (name, c, i))
+    return tot, ideal
+cands = {}
+for RS in (9, 10, 11):
+    for a in (0, 1, 2, 3):
+        for b in (0, 1, 2, 3, 5):
+            for sh in (2, 3):
+                cands[(RS, a, sh, b)] = (lambda RS=RS, a=a, b=b, sh=sh: (lambda row, m: row * RS + m + a * (row >> sh) + b * (row >> 4)))()
+res = sorted((evaluate(f)[0], k) for k, f in cands.items())
+print("best:", res[:8]); print("baseline (9,0,*,0):", evaluate(cands[(9, 0, 2, 0)]))
+best = res[0][1]; print("detail best", best); evaluate(cands[best], True); print("detail baseline"); evaluate(cands[(9,0,2,0)], True)
+size = lambda k: (64 * k[0] + k[1] * (63 >> k[2]) + k[3] * 3 + 9)
+print("tile elems best:", size(best))
+
+print("---- Latin-cube row permutation sigma(row)")
+def make_sigma(variant):
+    def sigma(row):
+        a, b, c = row >> 4, (row >> 2) & 3, row & 3
+        if variant == 0: g = 4 * ((a + c) & 3) + ((b + c) & 3); h = c
+        if variant == 1: g = 4 * ((a + c) & 3) + ((b + c) & 3); h = (c + b) & 3
+        if variant == 2: g = 4 * ((b + c) & 3) + ((a + c) & 3); h = c
+        if variant == 3: g = 4 * ((a + b + c) & 3) + ((b + 2 * c + a) & 3) ; h = c
+        if variant == 4: g = 4 * ((a + c) & 3) + ((b + c) & 3); h = (c + a) & 3
+        if variant == 5: g = 4 * ((a + c) & 3) + ((b + c) & 3); h = (c ^ 1)
+        return 16 * h + g
+    assert sorted(sigma(r) for r in range(64)) == list(range(64)), variant
+    return sigma
+for var in range(6):
+    try: sg = make_sigma(var)
+    except AssertionError: print("variant", var, "not a bijection"); continue
+    for pad in (0, 1):
+        f = lambda row, m, sg=sg, pad=pad: sg(row) * 9 + m + pad * (sg(row) >> 4)
+        t, i = evaluate(f)
+        print("variant", var, "pad", pad, "total", t)
+sg = make_sigma(0)
+print("detail variant 0"); evaluate(lambda row, m: sg(row) * 9 + m, True)
