@@ -222,7 +222,12 @@ def main():
                    "block_size": N, "batch_per_gpu": B, "sharding": "independent blocks per GPU, no data-path collective"},
         "msym_per_s": value * N / 1e6,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "kernel": dem.kernel_name() + " (demodulate, MF)", "bytes_per_launch": 16 * N * B,
+                     # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 [gfx950 correction, calibrated on a
+                     # copy kernel of the same access shape] + WRITE_SIZE; profiles/r01/pmc_hbm_traffic_summary.csv).
+                     # Counters cannot be read from inside this process, so the figure is only quoted for the
+                     # configuration it was measured on.
+                     "traffic": (18567 + 18432) * 1024 if (B == 4096 and dem.kernel_name() == "rowlane") else None,
+                     "kernel": dem.kernel_name() + " (demodulate, MF)", "bytes_per_launch": 16 * N * B,
                      "kernel_ms": kern_ms},
         "kernels": {"modulate": mod.kernel_name(), "demodulate": dem.kernel_name(), "advanced": adv.kernel_name()},
         "output_checksum": [float(v) for v in chk],

@@ -95,3 +95,19 @@ def test_product_sources_do_not_touch_the_oracle():
                 if re.search(r"gfdm_oracle|gfdm_ref|c_oracle|oracle/", text):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_reference_pybind_bindings_compile_unchanged():
+    """Drop-in evidence: gr-gfdm's own kernel bindings (python/bindings/{modulator,demodulator}_python.cc) compile,
+    unmodified and from where they lie, against this repository's class headers.  Build-container only: the
+    reference checkout does not exist on the GPU box."""
+    import subprocess
+    import sysconfig
+    import pybind11
+    ref = "/root/reference/python/bindings"
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present")
+    inc = ["-I" + os.path.join(ROOT, "gr-gfdm_amd", "cpp", "include"), "-I" + os.path.join(ROOT, "include"),
+           "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include()]
+    for name in ("modulator_python.cc", "demodulator_python.cc"):
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only"] + inc + [os.path.join(ref, name)])
