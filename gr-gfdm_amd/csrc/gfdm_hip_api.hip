@@ -122,10 +122,31 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
         }
 
     std::vector<cf> tables;
-    tables.reserve((size_t)ntaps + 3 * M + K + 2 * (size_t)N);
+    tables.reserve((size_t)ntaps + 4 * M + K + 2 * (size_t)N);
     tables.insert(tables.end(), pl.h_taps.begin(), pl.h_taps.end());
     tables.insert(tables.end(), pl.h_ictaps.begin(), pl.h_ictaps.end());
     for (int m = 0; m < M; ++m) tables.push_back(make_float2(pl.h_ictaps[m].x / (float)M, pl.h_ictaps[m].y / (float)M));
+    // g = IDFT_M(ic)/M in double: one IC round is d_new = d0 - g (*) (dec_{k-1} + dec_{k+1})  (gfdm_rowlane.hip)
+    bool ic_real_sym = true;
+    {
+        const double two_pi = 6.283185307179586476925286766559;
+        std::vector<double> gr(M), gi(M);
+        double gmax = 0.0;
+        for (int r = 0; r < M; ++r) {
+            double sr = 0.0, si = 0.0;
+            for (int m = 0; m < M; ++m) {
+                const double a = two_pi * (double)((r * m) % M) / (double)M;
+                sr += pl.h_ictaps[m].x * std::cos(a) - pl.h_ictaps[m].y * std::sin(a);
+                si += pl.h_ictaps[m].x * std::sin(a) + pl.h_ictaps[m].y * std::cos(a);
+            }
+            gr[r] = sr / M; gi[r] = si / M;
+            gmax = std::fmax(gmax, std::hypot(gr[r], gi[r]));
+        }
+        for (int r = 0; r < M; ++r) {
+            if (std::fabs(gi[r]) > 1e-7 * gmax || std::fabs(gr[r] - gr[(M - r) % M]) > 1e-7 * gmax) ic_real_sym = false;
+            tables.push_back(make_float2((float)gr[r], (float)gi[r]));
+        }
+    }
     unit_roots(tables, M);
     unit_roots(tables, K);
     unit_roots(tables, N);
@@ -152,7 +173,9 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     dp.taps = pl.d_tables;
     dp.ictaps = dp.taps + ntaps;
     dp.ictaps_m = dp.ictaps + M;
-    dp.wM = dp.ictaps_m + M;
+    dp.icg = dp.ictaps_m + M;
+    dp.ic_real_sym = ic_real_sym ? 1 : 0;
+    dp.wM = dp.icg + M;
     dp.wK = dp.wM + M;
     dp.wN = dp.wK + K;
     pl.d_twT = pl.d_tables + twT_off;

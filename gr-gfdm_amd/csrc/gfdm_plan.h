@@ -19,6 +19,8 @@ struct DevicePlan {
     const cf* taps;     // [L*M] normalised filter taps
     const cf* ictaps;   // [M]   ic[m] = t[m] * t[(L-1)M + m]
     const cf* ictaps_m; // [M]   ic[m] / M (IC taps with the inverse-DFT scale folded in)
+    const cf* icg;      // [M]   g = IDFT_M(ic) / M: circular-convolution form of one cancellation round
+    int ic_real_sym;    // 1 when g is real and even (real, even prototype filter): only g[0..M/2].x is used
     const cf* wM;       // [M]   exp(-2 pi j p / M)
     const cf* wK;       // [K]   exp(-2 pi j q / K)
     const cf* wN;       // [N]   exp(-2 pi j r / N)

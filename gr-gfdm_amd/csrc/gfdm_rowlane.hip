@@ -123,7 +123,7 @@ __device__ __forceinline__ cf decide_point(cf x, const IcParams& ic)
 }
 
 // =====================================================================================================================
-template <int K, int M, int L, int MODE, bool EQ>
+template <int K, int M, int L, int MODE, bool EQ, bool ICSYM>
 __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, IcParams ic, const cf* __restrict__ twT,
                                                                 cf* __restrict__ out, const cf* __restrict__ in,
                                                                 const cf* __restrict__ f_eq, int64_t nblocks)
@@ -183,8 +183,14 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     __syncthreads();                                      // every lane has read its neighbour rows: the tile is free
 
     if constexpr (MODE == RX_IC) {
+        // One cancellation round of the reference is  d_new = IDFT_M(S - ic (.) DFT_M(nb)) / M  with nb = dec_{k-1} + dec_{k+1}.
+        // Both transforms are linear, so  d_new = d0 - g (*) nb  with d0 = IDFT_M(S)/M (already in d) and the M-tap circular
+        // convolution kernel g = IDFT_M(ic)/M (host table p.icg).  For the usual real, even prototype filters ic is real and
+        // symmetric, hence g is too (ICSYM): M(M+1)/2 packed multiply-adds per row and round instead of two M-point DFTs.
         const int wgt = ic.active[q];                     // multiplicity of subcarrier k in subcarrier_map (0 = inactive)
         float* red = reinterpret_cast<float*>(reinterpret_cast<cf*>(smem) + S::BPW * T::TS);
+        cf d0[M];
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d0[m] = d[m]; });
         for (int it = 0; it < ic.ic_iter; ++it) {                                                        // adv:56-76
             const bool pc = (ic.do_phase_compensation > 0) && (it == 0);
             float acc = 0.f;
@@ -206,16 +212,41 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                 float sn, cs;
                 sincosf(phi, &sn, &cs);
                 const cf rot = mk(cs, sn);
-                static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = cmul(s[m], rot); });
+                static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d0[m] = cmul(d0[m], rot); });   // rotating S rotates d0
             }
             __syncthreads();
             const cf* below = X + ((q - 1 + K) & (K - 1)) * M;                                            // rx:274-299
             const cf* above = X + ((q + 1) & (K - 1)) * M;
             cf nb[M];
             static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; nb[m] = below[m] + above[m]; });
-            dft_inplace<M, false>(nb);
-            static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d[m] = s[m] - cmul(p.ictaps_m[m], nb[m]); });
-            dft_inplace<M, true>(d);
+            if constexpr (ICSYM) {
+                constexpr int H = (M - 1) / 2;
+                static_for<0, M>([&](auto pi) {
+                    constexpr int pp = decltype(pi)::value;
+                    cf acc = mk(fmaf(-p.icg[0].x, nb[pp].x, d0[pp].x), fmaf(-p.icg[0].x, nb[pp].y, d0[pp].y));
+                    static_for<1, H + 1>([&](auto ri) {
+                        constexpr int r = decltype(ri)::value;
+                        const cf pair = nb[(pp - r + M) % M] + nb[(pp + r) % M];
+                        acc = mk(fmaf(-p.icg[r].x, pair.x, acc.x), fmaf(-p.icg[r].x, pair.y, acc.y));
+                    });
+                    if constexpr (M % 2 == 0) {
+                        const cf mid = nb[(pp + M / 2) % M];
+                        acc = mk(fmaf(-p.icg[M / 2].x, mid.x, acc.x), fmaf(-p.icg[M / 2].x, mid.y, acc.y));
+                    }
+                    d[pp] = acc;
+                });
+            } else {
+                static_for<0, M>([&](auto pi) {
+                    constexpr int pp = decltype(pi)::value;
+                    cf acc = d0[pp];
+                    static_for<0, M>([&](auto ri) {
+                        constexpr int r = decltype(ri)::value;
+                        const cf g = p.icg[r], x = nb[(pp - r + M) % M];
+                        acc = mk(fmaf(-g.x, x.x, fmaf(g.y, x.y, acc.x)), fmaf(-g.x, x.y, fmaf(-g.y, x.x, acc.y)));
+                    });
+                    d[pp] = acc;
+                });
+            }
             __syncthreads();                              // all neighbour reads done before the tile is rewritten
         }
     }
@@ -284,10 +315,11 @@ hipError_t launch_rx(const DevicePlan& p, const IcParams& ic, const cf* twT, int
     constexpr size_t lds = row_lds_bytes<K, M>();
     static_assert(lds <= 64 * 1024, "row-lane tile exceeds the default dynamic LDS limit");
     const dim3 grid((unsigned)((nblocks + RowShape<K>::BPW - 1) / RowShape<K>::BPW)), block(RowShape<K>::WG);
-#define GFDM_RX(MODE_, EQ_) hipLaunchKernelGGL((k_row_receive<K, M, L, MODE_, EQ_>), grid, block, lds, st, p, ic, twT, out, in, f_eq, nblocks)
-    if (mode == RX_FD) { if (f_eq) GFDM_RX(RX_FD, true); else GFDM_RX(RX_FD, false); }
-    else if (mode == RX_DEMOD || ic.ic_iter <= 0) { if (f_eq) GFDM_RX(RX_DEMOD, true); else GFDM_RX(RX_DEMOD, false); }
-    else { if (f_eq) GFDM_RX(RX_IC, true); else GFDM_RX(RX_IC, false); }
+#define GFDM_RX(MODE_, EQ_, SYM_) hipLaunchKernelGGL((k_row_receive<K, M, L, MODE_, EQ_, SYM_>), grid, block, lds, st, p, ic, twT, out, in, f_eq, nblocks)
+    if (mode == RX_FD) { if (f_eq) GFDM_RX(RX_FD, true, false); else GFDM_RX(RX_FD, false, false); }
+    else if (mode == RX_DEMOD || ic.ic_iter <= 0) { if (f_eq) GFDM_RX(RX_DEMOD, true, false); else GFDM_RX(RX_DEMOD, false, false); }
+    else if (p.ic_real_sym) { if (f_eq) GFDM_RX(RX_IC, true, true); else GFDM_RX(RX_IC, false, true); }
+    else { if (f_eq) GFDM_RX(RX_IC, true, false); else GFDM_RX(RX_IC, false, false); }
 #undef GFDM_RX
     return hipGetLastError();
 }
