@@ -25,22 +25,54 @@
 
 #include <cstdlib>
 
+#ifndef GFDM_ROW_WG
+#define GFDM_ROW_WG 256
+#endif
+
 namespace gfdm {
 namespace {
 
 using namespace dft;
+
+// Diagnostic build only (-DGFDM_STAMPS, scratch/stamps.py): per-wave timestamps of the phase boundaries, written to a
+// side buffer that nothing else reads.  The product library is built without it.
+#ifdef GFDM_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define GFDM_STAMP(slot)                                                                                         \
+    do {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
+        if (g_stamp_buf && (threadIdx.x & 63) == 0)                                                               \
+            g_stamp_buf[((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GFDM_STAMP(slot) do { } while (0)
+#endif
 
 template <int K> struct RowShape {
     static constexpr int log2K = (K == 4) ? 2 : (K == 8) ? 3 : (K == 16) ? 4 : (K == 32) ? 5 : (K == 64) ? 6 : (K == 128) ? 7 : (K == 256) ? 8 : (K == 512) ? 9 : -1;
     static_assert(log2K > 0, "row-lane family supports K = 4 .. 512, power of two");
     static constexpr int NP4 = log2K / 2;
     static constexpr bool HAS2 = (log2K & 1) != 0;
-    static constexpr int WG = (K >= 64) ? K : 64;          // threads per workgroup
+    static constexpr int WG = (K >= 128) ? K : GFDM_ROW_WG;   // threads per workgroup (blocks of K <= 64 lanes are packed)
     static constexpr int BPW = WG / K;                     // blocks per workgroup
     static constexpr int RG = K / 4;                       // row groups of the FFT passes
 };
 
 constexpr int pow4(int s) { return 1 << (2 * s); }
+
+// Ordering point for the block's LDS tile.  A block of K <= 64 lanes lives inside ONE wavefront, whose LDS instructions
+// execute in program order: only the compiler has to be kept from reordering them (the other waves of the workgroup work
+// on other blocks and are never waited for).  Larger blocks span several waves and need the workgroup barrier.
+template <int K>
+__device__ __forceinline__ void block_sync()
+{
+    if constexpr (K <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
 
 // LDS tile: [row][M] complex, rows contiguous (M odd => conflict-free row access); tiles of one block are TS apart
 template <int K, int M> struct RowTile {
@@ -48,18 +80,40 @@ template <int K, int M> struct RowTile {
     static constexpr int TS = N + ((RowShape<K>::BPW > 1) ? 16 : 0);
 };
 
+// Row placement inside the tile WHILE the subcarrier FFT runs.  In natural order the autosort writes of the first radix-4
+// passes hit rows 4 tq + u resp. j + 16 qq + 4 u, whose b64 slots repeat every 4 lanes (4-way LDS bank conflict).  For
+// K = 64 the rows are therefore stored at slot sigma(row) = 16 c + 4 ((a + c) & 3) + ((b + c) & 3), row = 16 a + 4 b + c:
+// a Latin cube over the three radix-4 digits, so that every access pattern of every pass (and the row-per-lane write of
+// phase A) touches 16 different slots mod 16.  The LAST pass writes its output in natural order, which is what the
+// row-per-lane phases (equaliser, filter, IC, output) want.  Other K keep the natural order (correct, conflicted).
+template <int K> struct FftLayout {
+    static __device__ __forceinline__ int slot(int row) { return row; }
+};
+template <> struct FftLayout<64> {
+    static __device__ __forceinline__ int slot(int row)
+    {
+        const int a = row >> 4, b = (row >> 2) & 3, c = row & 3;
+        return 16 * c + 4 * ((a + c) & 3) + ((b + c) & 3);
+    }
+};
+
 // Radix-4 (and trailing radix-2) Stockham passes over the subcarrier axis, IN PLACE in one LDS tile: every lane first
 // pulls its 4 x CMAX inputs into registers, a barrier separates the reads from the (autosort-permuted) writes.
 // One tile instead of a ping-pong pair halves the LDS footprint, i.e. doubles the resident waves per CU.
+// Input rows are expected at FftLayout<K>::slot(row); the result is in natural row order.
 template <int K, int M, bool INV>
 __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const cf* __restrict__ wK)
 {
     using S = RowShape<K>;
+    using LY = FftLayout<K>;
     constexpr int RG = S::RG, CMAX = (M + 3) / 4;
     const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+    const cf* rb[4];
+    static_for<0, 4>([&](auto ri) { constexpr int r = decltype(ri)::value; rb[r] = tile + LY::slot(tq + RG * r) * M + c0; });
     static_for<0, S::NP4>([&](auto si) {
         constexpr int s = decltype(si)::value;
         constexpr int str = pow4(s), len = K / str, ms = len / 4;
+        constexpr bool last = (s == S::NP4 - 1) && !S::HAS2;      // the pass that leaves the data in natural order
         const int j = tq & (str - 1), qq = tq / str;
         cf w1, w2, w3;
         if constexpr (ms > 1) {
@@ -67,14 +121,18 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const cf*
             w2 = wK[(qq * 2 * str) & (K - 1)];
             w3 = wK[(qq * 3 * str) & (K - 1)];
         }
-        const cf* rb = tile + tq * M + c0;
-        cf* wb = tile + (j + 4 * str * qq) * M + c0;
+        cf* wb[4];
+        static_for<0, 4>([&](auto ui) {
+            constexpr int u = decltype(ui)::value;
+            const int row = j + 4 * str * qq + str * u;
+            wb[u] = tile + (last ? row : LY::slot(row)) * M + c0;
+        });
         cf x[CMAX][4];
         static_for<0, CMAX>([&](auto ci) {
             constexpr int c = decltype(ci)::value;
-            if (c0 + c < M) { x[c][0] = rb[c]; x[c][1] = rb[RG * M + c]; x[c][2] = rb[2 * RG * M + c]; x[c][3] = rb[3 * RG * M + c]; }
+            if (c0 + c < M) { x[c][0] = rb[0][c]; x[c][1] = rb[1][c]; x[c][2] = rb[2][c]; x[c][3] = rb[3][c]; }
         });
-        if constexpr (ms > 1) __syncthreads();            // last pass writes the rows it read: no hazard, no barrier
+        block_sync<K>();                                          // everyone has its inputs in registers
         static_for<0, CMAX>([&](auto ci) {
             constexpr int c = decltype(ci)::value;
             if (c0 + c < M) {
@@ -84,21 +142,27 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const cf*
                     x[c][2] = cmul_dir<INV>(x[c][2], w2);
                     x[c][3] = cmul_dir<INV>(x[c][3], w3);
                 }
-                wb[c] = x[c][0]; wb[str * M + c] = x[c][1]; wb[2 * str * M + c] = x[c][2]; wb[3 * str * M + c] = x[c][3];
+                wb[0][c] = x[c][0]; wb[1][c] = x[c][1]; wb[2][c] = x[c][2]; wb[3][c] = x[c][3];
             }
         });
-        __syncthreads();
+        block_sync<K>();
     });
-    if constexpr (S::HAS2) {      // len 2, stride K/2: pairs (tq, tq + K/2), (tq + K/4, tq + 3K/4); each lane owns its elements
+    if constexpr (S::HAS2) {      // len 2, stride K/2: pairs (tq, tq + K/2), (tq + K/4, tq + 3K/4); reads slots, writes natural rows
+        cf y[CMAX][4];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) { y[c][0] = rb[0][c]; y[c][1] = rb[1][c]; y[c][2] = rb[2][c]; y[c][3] = rb[3][c]; }
+        });
+        block_sync<K>();
         cf* b = tile + tq * M + c0;
         static_for<0, CMAX>([&](auto ci) {
             constexpr int c = decltype(ci)::value;
             if (c0 + c < M) {
-                const cf a0 = b[c], a1 = b[RG * M + c], a2 = b[2 * RG * M + c], a3 = b[3 * RG * M + c];
-                b[c] = a0 + a2; b[2 * RG * M + c] = a0 - a2; b[RG * M + c] = a1 + a3; b[3 * RG * M + c] = a1 - a3;
+                b[c] = y[c][0] + y[c][2]; b[2 * RG * M + c] = y[c][0] - y[c][2];
+                b[RG * M + c] = y[c][1] + y[c][3]; b[3 * RG * M + c] = y[c][1] - y[c][3];
             }
         });
-        __syncthreads();
+        block_sync<K>();
     }
 }
 
@@ -138,19 +202,25 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     const int64_t base = (valid ? blk : 0) * N;
     cf* X = reinterpret_cast<cf*>(smem) + g * T::TS;                   // the block's single LDS tile, [row][M]
 
+    GFDM_STAMP(0);
     // ---- phase A: timeslot DFT of row q, twiddle W_N^{q m}
     cf v[M];
     static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = in[base + K * pp + q]; });
     cf heq[EQ ? M : 1];
     if constexpr (EQ) static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; heq[i] = f_eq[base + q + K * i]; });
+    GFDM_STAMP(1);
     dft_inplace<M, false>(v);
-    X[q * M] = v[0];
-    static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = cmul(v[m], twT[m * K + q]); });
-    __syncthreads();
+    {
+        cf* xa = X + FftLayout<K>::slot(q) * M;                    // row q goes to its FFT slot
+        xa[0] = v[0];
+        static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = cmul(v[m], twT[m * K + q]); });
+    }
+    block_sync<K>();
 
     // ---- phase B: subcarrier FFT, in place
     lds_subcarrier_fft<K, M, false>(X, q, p.wK);
 
+    GFDM_STAMP(2);
     // ---- phase C: X[f] / f_eq[f] in linear order (a conj(b) / |b|^2, reciprocal by v_rcp_f32)              rx:315-316
     if constexpr (EQ) {
         static_for<0, M>([&](auto ii) {
@@ -159,7 +229,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
             const float inv = __builtin_amdgcn_rcpf(b.x * b.x + b.y * b.y);
             X[q + K * i] = mk((a.x * b.x + a.y * b.y) * inv, (a.y * b.x - a.x * b.y) * inv);
         });
-        __syncthreads();
+        block_sync<K>();
     }
 
     // ---- phase D: S[k][m] = sum_i taps[((i + L/2) % L) M + m] X[(k + i - L/2) mod K][m]                      rx:165-192
@@ -180,7 +250,8 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
         static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = scale(s[m], invM); d[m] = s[m]; });
         dft_inplace<M, true>(d);                                                                         // rx:211-225
     }
-    __syncthreads();                                      // every lane has read its neighbour rows: the tile is free
+    block_sync<K>();                                      // every lane has read its neighbour rows: the tile is free
+    GFDM_STAMP(3);
 
     if constexpr (MODE == RX_IC) {
         // One cancellation round of the reference is  d_new = IDFT_M(S - ic (.) DFT_M(nb)) / M  with nb = dec_{k-1} + dec_{k+1}.
@@ -194,17 +265,27 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
         for (int it = 0; it < ic.ic_iter; ++it) {                                                        // adv:56-76
             const bool pc = (ic.do_phase_compensation > 0) && (it == 0);
             float acc = 0.f;
-            static_for<0, M>([&](auto mi) {                                                              // adv:109-123
-                constexpr int m = decltype(mi)::value;
-                const cf dec = (wgt > 0) ? decide_point(d[m], ic) : mk(0.f, 0.f);
-                if (pc && wgt > 0) acc += (float)wgt * (atan2f(dec.y, dec.x) - atan2f(d[m].y, d[m].x));
-                X[q * M + m] = dec;
-            });
+            if (ic.decision == 1 && !pc) {
+                // QPSK hot path (constellation_qpsk::decision_maker: sign tests, zero -> negative point); the per-lane
+                // amplitudes are 0 on inactive subcarriers, so one compare + one select per component           adv:109-123
+                const float sp = (wgt > 0) ? 0.70710678118654752f : 0.f, sn = -sp;
+                static_for<0, M>([&](auto mi) {
+                    constexpr int m = decltype(mi)::value;
+                    X[q * M + m] = mk(d[m].x > 0.f ? sp : sn, d[m].y > 0.f ? sp : sn);
+                });
+            } else {
+                static_for<0, M>([&](auto mi) {                                                          // adv:109-123
+                    constexpr int m = decltype(mi)::value;
+                    const cf dec = (wgt > 0) ? decide_point(d[m], ic) : mk(0.f, 0.f);
+                    if (pc && wgt > 0) acc += (float)wgt * (atan2f(dec.y, dec.x) - atan2f(d[m].y, d[m].x));
+                    X[q * M + m] = dec;
+                });
+            }
             if (pc) {                                                                                    // adv:59-71, 78-91
                 for (int off = 1; off < 64 && off < K; off <<= 1) acc += __shfl_xor(acc, off, 64);
                 if constexpr (K > 64) {
                     if ((q & 63) == 0) red[q >> 6] = acc;
-                    __syncthreads();
+                    block_sync<K>();
                     acc = 0.f;
                     static_for<0, K / 64>([&](auto wi) { acc += red[decltype(wi)::value]; });
                 }
@@ -214,7 +295,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                 const cf rot = mk(cs, sn);
                 static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d0[m] = cmul(d0[m], rot); });   // rotating S rotates d0
             }
-            __syncthreads();
+            block_sync<K>();
             const cf* below = X + ((q - 1 + K) & (K - 1)) * M;                                            // rx:274-299
             const cf* above = X + ((q + 1) & (K - 1)) * M;
             cf nb[M];
@@ -247,16 +328,18 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                     d[pp] = acc;
                 });
             }
-            __syncthreads();                              // all neighbour reads done before the tile is rewritten
+            block_sync<K>();                              // all neighbour reads done before the tile is rewritten
         }
     }
 
+    GFDM_STAMP(4);
     // ---- output: row -> tile, linear read, coalesced store
     static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = (MODE == RX_FD) ? s[m] : d[m]; });
-    __syncthreads();
+    block_sync<K>();
     if (valid) {
         static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; out[base + q + K * i] = X[q + K * i]; });
     }
+    GFDM_STAMP(5);
 }
 
 // =====================================================================================================================
@@ -277,12 +360,12 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
 
     // symbols [k][p], copied linearly (coalesced) into the tile; lane k then owns row k
     static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; X[q + K * i] = in[base + q + K * i]; });
-    __syncthreads();
+    block_sync<K>();
     cf v[M];
     static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = X[q * M + m]; });
     dft_inplace<M, false>(v);                                                                          // mod:109-110
     static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = v[m]; });    // own row: no hazard
-    __syncthreads();
+    block_sync<K>();
     // gather form of filter + overlap-add: Y[j][m] = sum_i D[(j - i + L/2) mod K][m] taps[((i + L/2) % L) M + m]   mod:116-132
     constexpr float invN = 1.0f / (float)N;
     static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = mk(0.f, 0.f); });
@@ -294,9 +377,12 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
             v[m] = cfma(rb[m], p.taps[((i + L / 2) % L) * M + m], v[m]);
         });
     });
-    __syncthreads();                                      // neighbour rows read by everyone before they are overwritten
-    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = scale(v[m], invN); });
-    __syncthreads();
+    block_sync<K>();                                      // neighbour rows read by everyone before they are overwritten
+    {
+        cf* xa = X + FftLayout<K>::slot(q) * M;
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = scale(v[m], invN); });
+    }
+    block_sync<K>();
     lds_subcarrier_fft<K, M, true>(X, q, p.wK);                                                         // inverse over j
     v[0] = X[q * M];
     static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = cmulc(X[q * M + m], twT[m * K + q]); });
@@ -340,6 +426,10 @@ hipError_t launch_mod(const DevicePlan& p, const cf* twT, cf* out, const cf* in,
     X(32, 5, 2)            \
     X(32, 9, 2)            \
     X(128, 15, 4)
+
+#ifdef GFDM_STAMPS
+extern "C" int gfdm_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)); }
+#endif
 
 bool rowlane_supports(int M, int K, int L)
 {

@@ -13,7 +13,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.normpath(os.path.join(_PKG, "..", "..", "lib"))
-LIB_PATH = os.path.join(LIB_DIR, "libgfdm_hip.so")
+LIB_PATH = os.environ.get("GFDM_HIP_LIB") or os.path.join(LIB_DIR, "libgfdm_hip.so")   # override: A/B builds of the kernels
 
 OK, EINVAL_TAPS, EINVAL_OVERLAP, EINVAL, ENODEV, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
 DECIDE = {"auto": -1, "nearest": 0, "qpsk": 1, "bpsk": 2}
