@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="GFDM blocks per step and per GPU (configs[1]: 4096)")
     ap.add_argument("--ring-mib", type=int, default=2048, help="total footprint of the buffer ring per path")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps of the headline loop are pipelined over")
+    ap.add_argument("--large-batch", type=int, default=65536, help="blocks per launch of the extra large-batch measurement (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the per-variant measurements")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of each cpu_baseline leg")
@@ -74,35 +76,41 @@ def raw_launcher(fn, handle, out_t, in_ts, nblocks, stream_ptr):
     return go
 
 
-def timed_loop(step_fns, dominant, steps, warmup, world):
-    """Run warmup + `steps` timed steps.  step_fns[i] is a list of launch closures for ring slot i;
-    `dominant` is the index (within a step) of the kernel the roofline describes.
-    Returns (wall seconds of the timed region, mean duration in ms of the dominant kernel from HIP events)."""
+def timed_loop(step_fns, dominant, steps, warmup, world, time_kernel=True):
+    """Run warmup + `steps` timed steps.  step_fns[i] is the list of launch closures of ring slot i (each closure is bound
+    to its stream); `dominant` is the index (within a step) of the kernel the roofline describes.  With `time_kernel` a
+    HIP event pair is recorded on the launch stream around every launch of that kernel (single-stream loops only).
+    Returns (wall seconds of the timed region, mean event-bracketed duration in ms of the dominant kernel or None)."""
     nslots = len(step_fns)
     for i in range(warmup):
         for f in step_fns[i % nslots]:
             f()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if time_kernel else None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        fns = step_fns[(warmup + i) % nslots]
-        for j, f in enumerate(fns):
-            if j == dominant:         # HIP events on the launch stream (torch's current stream) around every launch
-                ev[i][0].record()
-                f()
-                ev[i][1].record()
-            else:
+    if time_kernel:
+        for i in range(steps):
+            fns = step_fns[(warmup + i) % nslots]
+            for j, f in enumerate(fns):
+                if j == dominant:         # HIP events on the launch stream (torch's current stream) around the launch
+                    ev[i][0].record()
+                    f()
+                    ev[i][1].record()
+                else:
+                    f()
+    else:
+        for i in range(steps):
+            for f in step_fns[(warmup + i) % nslots]:
                 f()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms = float(np.mean([x.elapsed_time(y) for x, y in ev])) if time_kernel else None
     return wall, kern_ms
 
 
@@ -200,17 +208,29 @@ def main():
     gblock = lambda s: (rank * 1000003 + s) * B          # distinct global block range per rank and slot
 
     # ---- headline: mod + MF demod -------------------------------------------------------------------------------
-    ns = slots(3)
+    # Steps are independent batches (own ring slot each), so they are pipelined over `--streams` HIP streams: slot s always
+    # runs on stream s % S, i.e. within a stream modulate -> demodulate of a slot stay ordered while the load / compute /
+    # store phases of neighbouring steps overlap on the GPU.  `value` is timed on that region.  The `roofline` object is
+    # taken from a single-stream replay of the same steps (one kernel on the GPU at a time) with a HIP event pair around
+    # every launch of the dominant kernel, so that its duration is that kernel's own.
+    S = max(1, a.streams)
+    ns = max(S, (slots(3) // S) * S)
     sym = [synth.qpsk_symbols(gblock(s), B, N, dev) for s in range(ns)]
     frames = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(ns)]
     outs = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(ns)]
-    steps_fns = [[raw_launcher(L_.gfdm_hip_modulator_work_device, mod._h, frames[s], [sym[s]], B, stream),
-                  raw_launcher(L_.gfdm_hip_receiver_demodulate_device, dem._h, outs[s], [frames[s], None], B, stream)]
-                 for s in range(ns)]
-    wall, kern_ms = timed_loop(steps_fns, 1, a.steps, a.warmup, world)
+    side = [torch.cuda.Stream(device=dev) for _ in range(S)]
+
+    def step_fns_on(stream_of_slot):
+        return [[raw_launcher(L_.gfdm_hip_modulator_work_device, mod._h, frames[s], [sym[s]], B, stream_of_slot(s)),
+                 raw_launcher(L_.gfdm_hip_receiver_demodulate_device, dem._h, outs[s], [frames[s], None], B, stream_of_slot(s))]
+                for s in range(ns)]
+
+    wall, _ = timed_loop(step_fns_on(lambda s: side[s % S].cuda_stream), 1, a.steps, a.warmup, world, time_kernel=False)
     chk = sharding.output_checksum(outs[(a.warmup + a.steps - 1) % ns])
     total_blocks, chk, wall_max = sharding.reduce_stats(B * a.steps, chk, wall, dev)
     value = total_blocks / wall_max
+    wall1, kern_ms = timed_loop(step_fns_on(lambda s: stream), 1, a.steps, a.warmup, world, time_kernel=True)
+    _, _, wall1_max = sharding.reduce_stats(0, torch.zeros(3, dtype=torch.float64, device=dev), wall1, dev)
     achieved = 16.0 * N * B / (kern_ms * 1e-3) / 1e9
     result = {
         "metric": "GFDM blocks/s, K=64 M=9 mod+demod (MF), batch 4096 per GPU",
@@ -218,9 +238,12 @@ def main():
         "ms_per_step": wall_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: K=64 subcarriers, M=9 timeslots, RRC alpha=0.2, overlap=2, MF receiver, "
-                               "%d QPSK blocks per step per GPU, step = modulate + demodulate, ring of %d buffer sets" % (B, ns),
-                   "block_size": N, "batch_per_gpu": B, "sharding": "independent blocks per GPU, no data-path collective"},
+                               "%d QPSK blocks per step per GPU, step = modulate + demodulate, ring of %d buffer sets, "
+                               "independent steps pipelined over %d HIP streams" % (B, ns, S),
+                   "block_size": N, "batch_per_gpu": B, "streams": S,
+                   "sharding": "independent blocks per GPU, no data-path collective"},
         "msym_per_s": value * N / 1e6,
+        "value_single_stream": world * B * a.steps / wall1_max,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 [gfx950 correction, calibrated on a
                      # copy kernel of the same access shape] + WRITE_SIZE; profiles/r01/pmc_hbm_traffic_summary.csv).
@@ -228,11 +251,12 @@ def main():
                      # configuration it was measured on.
                      "traffic": (18567 + 18432) * 1024 if (B == 4096 and dem.kernel_name() == "rowlane") else None,
                      "kernel": dem.kernel_name() + " (demodulate, MF)", "bytes_per_launch": 16 * N * B,
-                     "kernel_ms": kern_ms},
+                     "kernel_ms": kern_ms,
+                     "region": "single-stream replay of the %d timed steps, HIP event pair around every demodulate launch" % a.steps},
         "kernels": {"modulate": mod.kernel_name(), "demodulate": dem.kernel_name(), "advanced": adv.kernel_name()},
         "output_checksum": [float(v) for v in chk],
     }
-    del sym, frames, outs, steps_fns
+    del sym, frames, outs
 
     # ---- per-variant measurements (each alone on the stream, own ring) ----------------------------------------------
     if not a.no_paths:
@@ -281,6 +305,33 @@ def main():
         result["paths"] = paths
         result["north_star"] = {"path": "demod_zf_ic2 (BASELINE configs[2]: ZF demod + 2 IC iterations)",
                                 "frac_of_hbm_peak": paths["demod_zf_ic2"]["frac_of_hbm_peak"], "target": 0.40}
+
+    # ---- the same kernels at the batch size of BASELINE configs[3,4] (65 536 blocks per launch): steady-state roofline --------
+    if a.large_batch > 0 and not a.no_paths:
+        BL = a.large_batch
+        large = {}
+        nsl = 3
+        for name, fn, handle, with_eq, bps in (("demod_mf", L_.gfdm_hip_receiver_demodulate_device, dem._h, False, 16),
+                                               ("demod_zf_ic2", L_.gfdm_hip_advanced_receiver_work_device, adv._h, True, 24)):
+            fr, eq, o = [], [], []
+            for sl in range(nsl):
+                x = mod.modulate(synth.qpsk_symbols(gblock(1000 + sl) , BL, N, dev))
+                if with_eq:
+                    f = synth.channel_response(gblock(1000 + sl), BL, N, dev)
+                    x = synth.through_channel(x, f)
+                    eq.append(f)
+                fr.append(x)
+                o.append(torch.empty(BL, N, dtype=torch.complex64, device=dev))
+            torch.cuda.synchronize()
+            fns = [[raw_launcher(fn, handle, o[sl], [fr[sl], eq[sl] if with_eq else None], BL, stream)] for sl in range(nsl)]
+            nst = max(10, a.steps // 8)
+            w, kms = timed_loop(fns, 0, nst, 3, world)
+            _, _, wmax = sharding.reduce_stats(0, torch.zeros(3, dtype=torch.float64, device=dev), w, dev)
+            gbps = bps * N * BL / (kms * 1e-3) / 1e9
+            large[name] = {"blocks_per_launch": BL, "blocks_per_s": world * BL * nst / wmax, "kernel_ms": kms,
+                           "bytes_per_launch": bps * N * BL, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+            del fr, eq, o, fns
+        result["large_batch"] = large
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(taps, B, a.cpu_seconds)
