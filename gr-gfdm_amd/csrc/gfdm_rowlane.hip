@@ -166,6 +166,16 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const cf*
     }
 }
 
+// lane i <- lane (i -+ 1) mod 64: DPP wave rotates (GFX9 dpp_ctrl 0x13C = wave_ror:1, 0x134 = wave_rol:1)
+__device__ __forceinline__ float dpp_wave_ror1(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_wave_rol1(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x134, 0xF, 0xF, false));
+}
+
 __device__ __forceinline__ cf decide_point(cf x, const IcParams& ic)
 {
     if (ic.decision == 1) {
@@ -206,16 +216,26 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     // ---- phase A: timeslot DFT of row q, twiddle W_N^{q m}
     cf v[M];
     static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = in[base + K * pp + q]; });
-    cf heq[EQ ? M : 1];
-    if constexpr (EQ) static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; heq[i] = f_eq[base + q + K * i]; });
+    cf tw[M];
+    static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; tw[m] = twT[m * K + q]; });
     GFDM_STAMP(1);
     dft_inplace<M, false>(v);
     {
         cf* xa = X + FftLayout<K>::slot(q) * M;                    // row q goes to its FFT slot
         xa[0] = v[0];
-        static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = cmul(v[m], twT[m * K + q]); });
+        static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = cmul(v[m], tw[m]); });
     }
     block_sync<K>();
+    // The equaliser vector is needed only after the subcarrier FFT: request it now, behind every wave's sample loads
+    // (HBM serves requests roughly in issue order, so the samples of all waves arrive first and the transforms start
+    // earlier; f_eq streams in while phases A/B run).
+    cf heq[EQ ? M : 1];
+    if constexpr (EQ) {
+#ifndef GFDM_EAGER_FEQ
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; heq[i] = f_eq[base + q + K * i]; });
+    }
 
     // ---- phase B: subcarrier FFT, in place
     lds_subcarrier_fft<K, M, false>(X, q, p.wK);
@@ -265,20 +285,20 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
         for (int it = 0; it < ic.ic_iter; ++it) {                                                        // adv:56-76
             const bool pc = (ic.do_phase_compensation > 0) && (it == 0);
             float acc = 0.f;
+            cf dec[M];
             if (ic.decision == 1 && !pc) {
                 // QPSK hot path (constellation_qpsk::decision_maker: sign tests, zero -> negative point); the per-lane
                 // amplitudes are 0 on inactive subcarriers, so one compare + one select per component           adv:109-123
                 const float sp = (wgt > 0) ? 0.70710678118654752f : 0.f, sn = -sp;
                 static_for<0, M>([&](auto mi) {
                     constexpr int m = decltype(mi)::value;
-                    X[q * M + m] = mk(d[m].x > 0.f ? sp : sn, d[m].y > 0.f ? sp : sn);
+                    dec[m] = mk(d[m].x > 0.f ? sp : sn, d[m].y > 0.f ? sp : sn);
                 });
             } else {
                 static_for<0, M>([&](auto mi) {                                                          // adv:109-123
                     constexpr int m = decltype(mi)::value;
-                    const cf dec = (wgt > 0) ? decide_point(d[m], ic) : mk(0.f, 0.f);
-                    if (pc && wgt > 0) acc += (float)wgt * (atan2f(dec.y, dec.x) - atan2f(d[m].y, d[m].x));
-                    X[q * M + m] = dec;
+                    dec[m] = (wgt > 0) ? decide_point(d[m], ic) : mk(0.f, 0.f);
+                    if (pc && wgt > 0) acc += (float)wgt * (atan2f(dec[m].y, dec[m].x) - atan2f(d[m].y, d[m].x));
                 });
             }
             if (pc) {                                                                                    // adv:59-71, 78-91
@@ -295,11 +315,22 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                 const cf rot = mk(cs, sn);
                 static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d0[m] = cmul(d0[m], rot); });   // rotating S rotates d0
             }
-            block_sync<K>();
-            const cf* below = X + ((q - 1 + K) & (K - 1)) * M;                                            // rx:274-299
-            const cf* above = X + ((q + 1) & (K - 1)) * M;
+            // neighbours k-1 and k+1 (wrap mod K)                                                           rx:274-299
             cf nb[M];
-            static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; nb[m] = below[m] + above[m]; });
+            if constexpr (K == 64) {
+                // the block IS the wavefront: subcarrier k +- 1 is lane +- 1 with wrap-around, i.e. a DPP wave rotate --
+                // no LDS traffic and no ordering point in the whole cancellation round
+                static_for<0, M>([&](auto mi) {
+                    constexpr int m = decltype(mi)::value;
+                    nb[m] = mk(dpp_wave_ror1(dec[m].x) + dpp_wave_rol1(dec[m].x), dpp_wave_ror1(dec[m].y) + dpp_wave_rol1(dec[m].y));
+                });
+            } else {
+                static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = dec[m]; });
+                block_sync<K>();
+                const cf* below = X + ((q - 1 + K) & (K - 1)) * M;
+                const cf* above = X + ((q + 1) & (K - 1)) * M;
+                static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; nb[m] = below[m] + above[m]; });
+            }
             if constexpr (ICSYM) {
                 constexpr int H = (M - 1) / 2;
                 static_for<0, M>([&](auto pi) {
@@ -328,7 +359,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                     d[pp] = acc;
                 });
             }
-            block_sync<K>();                              // all neighbour reads done before the tile is rewritten
+            if constexpr (K != 64) block_sync<K>();       // all neighbour reads done before the tile is rewritten
         }
     }
 
@@ -425,7 +456,8 @@ hipError_t launch_mod(const DevicePlan& p, const cf* twT, cf* out, const cf* in,
     X(64, 9, 2)            \
     X(32, 5, 2)            \
     X(32, 9, 2)            \
-    X(128, 15, 4)
+    X(128, 15, 4)          \
+    X(256, 31, 2)
 
 #ifdef GFDM_STAMPS
 extern "C" int gfdm_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)); }
