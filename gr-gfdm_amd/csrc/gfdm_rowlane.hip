@@ -395,19 +395,33 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
     cf v[M];
     static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = X[q * M + m]; });
     dft_inplace<M, false>(v);                                                                          // mod:109-110
-    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = v[m]; });    // own row: no hazard
-    block_sync<K>();
     // gather form of filter + overlap-add: Y[j][m] = sum_i D[(j - i + L/2) mod K][m] taps[((i + L/2) % L) M + m]   mod:116-132
     constexpr float invN = 1.0f / (float)N;
-    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = mk(0.f, 0.f); });
-    static_for<0, L>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        const cf* rb = X + ((q - i + L / 2 + K) & (K - 1)) * M;
-        static_for<0, PART>([&](auto mi) {
+    if constexpr (K == 64 && L == 2) {
+        // the block is the wavefront and the only foreign row is j + 1: fetch it with a DPP wave rotate, no LDS round trip
+        static_for<0, M>([&](auto mi) {
             constexpr int m = decltype(mi)::value;
-            v[m] = cfma(rb[m], p.taps[((i + L / 2) % L) * M + m], v[m]);
+            const cf up = mk(dpp_wave_rol1(v[m].x), dpp_wave_rol1(v[m].y));          // D[(j + 1) mod K][m]   (i = 0)
+            cf acc = mk(0.f, 0.f);
+            if constexpr (m < PART) {
+                acc = cfma(up, p.taps[M + m], acc);
+                acc = cfma(v[m], p.taps[m], acc);                                     // D[j][m]              (i = 1)
+            }
+            v[m] = acc;
         });
-    });
+    } else {
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = v[m]; });    // own row: no hazard
+        block_sync<K>();
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = mk(0.f, 0.f); });
+        static_for<0, L>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const cf* rb = X + ((q - i + L / 2 + K) & (K - 1)) * M;
+            static_for<0, PART>([&](auto mi) {
+                constexpr int m = decltype(mi)::value;
+                v[m] = cfma(rb[m], p.taps[((i + L / 2) % L) * M + m], v[m]);
+            });
+        });
+    }
     block_sync<K>();                                      // neighbour rows read by everyone before they are overwritten
     {
         cf* xa = X + FftLayout<K>::slot(q) * M;
