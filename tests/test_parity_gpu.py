@@ -329,3 +329,48 @@ def test_full_size_properties(name, M, K, L, alpha, B):
     lhs = (dem.demodulate(g).conj().to(torch.complex128) * w).sum(dim=-1)
     rhs = (N / M) * (g.conj().to(torch.complex128) * modc.modulate(w)).sum(dim=-1)
     assert float(((lhs - rhs).abs() / lhs.abs().clamp_min(1e-3)).max()) < 1e-3
+
+
+def test_baseline_shapes_run_on_the_tuned_family():
+    """BASELINE configs 1-5 must be served by the tuned row-lane kernels, every other shape by the generic family
+    (both are HIP; this guards against silently benchmarking the slow path)."""
+    import gfdm_amd
+    for (M, K, L, alpha) in SHAPES[:4]:
+        taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+        assert gfdm_amd.Modulator(M, K, L, taps).kernel_name() == "rowlane"
+        assert gfdm_amd.Demodulator(M, K, L, taps).kernel_name() == "rowlane"
+        assert gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points()).kernel_name() == "rowlane"
+    taps = get_frequency_domain_filter("rrc", 0.35, 25, 96, 2)
+    assert gfdm_amd.Demodulator(25, 96, 2, taps).kernel_name() == "generic_lds"
+
+
+def test_ic_with_complex_asymmetric_taps_uses_general_convolution():
+    """The IC rounds use the real-symmetric convolution kernel only when g = IDFT(ic)/M is real and even; arbitrary
+    complex taps must take the general path and still match the oracle."""
+    import gfdm_amd
+    rng = np.random.default_rng(11)
+    for (M, K, L) in ((9, 64, 2), (15, 128, 4), (5, 32, 2)):
+        taps = rng.standard_normal(M * L) + 1j * rng.standard_normal(M * L)
+        nt = R.normalize_taps(taps, M)
+        B, N = 5, M * K
+        d = qpsk(rng, (B, N))
+        x = R.modulate(d, nt, M, K, L) + 0.05 * (rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N)))
+        adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+        ref, st = R.advanced_receive(x, nt, M, K, L, np.arange(K), R.qpsk_points(), 2, kind="qpsk", return_stages=True)
+        keep = guarded(st, np.arange(K), K, M)
+        assert keep.sum() >= 3
+        assert rel_err(adv.demodulate(x)[keep], ref[keep]) < TOL
+
+
+def test_all_zero_and_tie_inputs_follow_the_reference_decision_rule():
+    """decision_maker is '> 0': an exactly-zero component maps to the NEGATIVE point."""
+    import gfdm_amd
+    M, K, L = 9, 64, 2
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+    x = np.zeros((2, M * K), np.complex64)
+    ref = R.advanced_receive(x, nt, M, K, L, np.arange(K), R.qpsk_points(), 2, kind="qpsk")
+    got = adv.demodulate(x)
+    assert np.abs(ref).max() > 0.01            # the all-negative decisions leave a non-zero cancellation term
+    assert rel_err(got, ref) < TOL
