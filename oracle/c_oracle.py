@@ -46,6 +46,13 @@ def load(path=None):
     lib.gfdm_oracle_demodulate.argtypes = [vp, vp, vp, vp, lg]
     lib.gfdm_oracle_advanced_receive.argtypes = [vp, vp, vp, vp, lg, vp, ctypes.c_int, vp, ctypes.c_int,
                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.gfdm_oracle_tx_create.restype = vp
+    lib.gfdm_oracle_tx_create.argtypes = [ctypes.c_int] * 6 + [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp,
+                                          ctypes.c_int, vp, ctypes.c_int]
+    lib.gfdm_oracle_tx_destroy.argtypes = [vp]
+    lib.gfdm_oracle_tx_input_vector_size.argtypes = [vp]
+    lib.gfdm_oracle_tx_output_vector_size.argtypes = [vp]
+    lib.gfdm_oracle_tx_work.argtypes = [vp, vp, vp, ctypes.c_int, lg, ctypes.c_int]
     del fp, ip
     if path is None:
         _LIB = lib
@@ -113,3 +120,29 @@ class COracle:
         return self._run(self.lib.gfdm_oracle_advanced_receive, x, f_eq,
                          extra=(smap.ctypes.data, smap.size, pts.ctypes.data, pts.size, DECIDE[kind], ic_iter,
                                 do_phase_compensation))
+
+
+class COracleTx:
+    """Composite transmitter oracle (mapper -> modulator -> cyclic prefix + ramp -> preamble), one port per call."""
+
+    def __init__(self, M, K, A, cp, cs, ramp, smap, per_timeslot, L, taps, window, shifts, preambles, lib=None):
+        self.lib = lib or load()
+        t = _c64(taps); w = _c64(window); p = _c64(np.atleast_2d(preambles))
+        sm = np.ascontiguousarray(smap, np.int32); sh = np.ascontiguousarray(shifts, np.int32)
+        self.h = self.lib.gfdm_oracle_tx_create(M, K, A, cp, cs, ramp, sm.ctypes.data, int(per_timeslot), L, t.ctypes.data, t.size,
+                                                w.ctypes.data, w.size, sh.ctypes.data, sh.size, p.ctypes.data, p.shape[1])
+        if not self.h:
+            raise ValueError("invalid transmitter configuration")
+        self.n_in = self.lib.gfdm_oracle_tx_input_vector_size(self.h)
+        self.n_out = self.lib.gfdm_oracle_tx_output_vector_size(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.gfdm_oracle_tx_destroy(self.h)
+            self.h = None
+
+    def work(self, symbols, port=0):
+        x = _c64(np.atleast_2d(symbols))
+        out = np.empty((x.shape[0], self.n_out), np.complex64)
+        self.lib.gfdm_oracle_tx_work(self.h, out.ctypes.data, x.ctypes.data, x.shape[1], x.shape[0], port)
+        return out

@@ -381,3 +381,81 @@ void gfdm_oracle_advanced_receive(gfdm_oracle* o, float* out_f, const float* in_
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Composite transmitter: restates lib/resource_mapper_kernel_cc.cc:74-89,108-134 (map_to_resources),
+ * lib/add_cyclic_prefix_cc.cc:66-98 (cyclic extension with shift, ramp) and lib/transmitter_kernel.cc:78-107. */
+struct gfdm_oracle_tx {
+    gfdm_oracle* mod;
+    int M, K, A, cp, cs, ramp, per_timeslot, nshifts, plen;
+    int* smap;            /* sorted, as the reference constructor leaves it */
+    int* shifts;
+    cf *front, *back;     /* ramp_len taps each */
+    cf* preambles;        /* nshifts x plen */
+    cf *mapped, *frame;   /* N each */
+};
+
+static int cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+
+gfdm_oracle_tx* gfdm_oracle_tx_create(int M, int K, int A, int cp, int cs, int ramp, const int* smap, int per_timeslot, int L,
+                                      const float* taps, int ntaps, const float* window, int n_window, const int* shifts, int nshifts,
+                                      const float* preambles, int plen)
+{
+    const int N = M * K;
+    if (A > K || A < 1 || nshifts < 1 || plen < 0) return NULL;
+    if (n_window != N + cp + cs && n_window != 2 * ramp) return NULL;
+    gfdm_oracle* mod = gfdm_oracle_create(M, K, L, taps, ntaps);
+    if (!mod) return NULL;
+    gfdm_oracle_tx* t = (gfdm_oracle_tx*)calloc(1, sizeof(*t));
+    t->mod = mod; t->M = M; t->K = K; t->A = A; t->cp = cp; t->cs = cs; t->ramp = ramp; t->per_timeslot = per_timeslot;
+    t->nshifts = nshifts; t->plen = plen;
+    t->smap = (int*)malloc(sizeof(int) * A); memcpy(t->smap, smap, sizeof(int) * A); qsort(t->smap, A, sizeof(int), cmp_int);
+    t->shifts = (int*)malloc(sizeof(int) * nshifts); memcpy(t->shifts, shifts, sizeof(int) * nshifts);
+    t->front = (cf*)malloc(sizeof(cf) * (ramp > 0 ? ramp : 1)); t->back = (cf*)malloc(sizeof(cf) * (ramp > 0 ? ramp : 1));
+    memcpy(t->front, window, sizeof(cf) * ramp);
+    memcpy(t->back, (const cf*)window + (n_window - ramp), sizeof(cf) * ramp);
+    t->preambles = (cf*)malloc(sizeof(cf) * (size_t)nshifts * (plen > 0 ? plen : 1));
+    memcpy(t->preambles, preambles, sizeof(cf) * (size_t)nshifts * plen);
+    t->mapped = (cf*)malloc(sizeof(cf) * N); t->frame = (cf*)malloc(sizeof(cf) * N);
+    return t;
+}
+
+void gfdm_oracle_tx_destroy(gfdm_oracle_tx* t)
+{
+    if (!t) return;
+    gfdm_oracle_destroy(t->mod);
+    free(t->smap); free(t->shifts); free(t->front); free(t->back); free(t->preambles); free(t->mapped); free(t->frame); free(t);
+}
+
+int gfdm_oracle_tx_input_vector_size(const gfdm_oracle_tx* t) { return t->A * t->M; }
+int gfdm_oracle_tx_output_vector_size(const gfdm_oracle_tx* t) { return t->plen + t->cp + t->M * t->K + t->cs; }
+
+void gfdm_oracle_tx_work(gfdm_oracle_tx* t, float* out_f, const float* in_f, int nin, long nblocks, int port)
+{
+    const int M = t->M, K = t->K, A = t->A, N = M * K, F = gfdm_oracle_tx_output_vector_size(t);
+    const int shift = t->shifts[port];
+    for (long b = 0; b < nblocks; ++b) {
+        const cf* in = (const cf*)in_f + b * nin;
+        cf* out = (cf*)out_f + b * F;
+        memset(t->mapped, 0, sizeof(cf) * N);                                   /* map_to_resources */
+        int ctr = 0;
+        if (t->per_timeslot) {
+            for (int ti = 0; ti < M; ++ti)
+                for (int a = 0; a < A; ++a, ++ctr)
+                    if (ctr < nin) t->mapped[M * t->smap[a] + ti] = in[ctr];
+        } else {
+            for (int a = 0; a < A; ++a)
+                for (int ti = 0; ti < M; ++ti, ++ctr)
+                    if (ctr < nin) t->mapped[M * t->smap[a] + ti] = in[ctr];
+        }
+        modulate_block(t->mod, t->frame, t->mapped);
+        memcpy(out, t->preambles + (size_t)port * t->plen, sizeof(cf) * t->plen);   /* insert_preamble */
+        cf* body = out + t->plen;                                                /* add_cyclic_extension */
+        const int scp = t->cp + shift, scs = t->cs - shift;
+        memcpy(body, t->frame + (N - scp), sizeof(cf) * scp);
+        memcpy(body + scp, t->frame, sizeof(cf) * N);
+        memcpy(body + scp + N, t->frame, sizeof(cf) * scs);
+        const int tail = N + t->cp + t->cs - t->ramp;                             /* apply_ramp */
+        for (int i = 0; i < t->ramp; ++i) { body[i] = cf_mul(body[i], t->front[i]); body[tail + i] = cf_mul(body[tail + i], t->back[i]); }
+    }
+}

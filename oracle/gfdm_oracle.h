@@ -33,6 +33,20 @@ void gfdm_oracle_advanced_receive(gfdm_oracle* o, float* out, const float* in, c
                                   const int* subcarrier_map, int nsubcarrier_map, const float* points, int npoints,
                                   int decision_kind, int ic_iter, int do_phase_compensation);
 
+/* ---- composite transmitter: mapper -> modulator -> cyclic prefix/suffix + ramp -> preamble ---- */
+typedef struct gfdm_oracle_tx gfdm_oracle_tx;
+/* window: n_window complex taps (whole window or 2*ramp_len); preambles: n_shifts rows of preamble_len complex.
+ * Returns NULL on the argument errors the reference constructors throw for. */
+gfdm_oracle_tx* gfdm_oracle_tx_create(int timeslots, int subcarriers, int active_subcarriers, int cp_len, int cs_len, int ramp_len,
+                                      const int* subcarrier_map, int per_timeslot, int overlap, const float* taps, int ntaps,
+                                      const float* window, int n_window, const int* cyclic_shifts, int n_shifts,
+                                      const float* preambles, int preamble_len);
+void gfdm_oracle_tx_destroy(gfdm_oracle_tx* t);
+int gfdm_oracle_tx_input_vector_size(const gfdm_oracle_tx* t);
+int gfdm_oracle_tx_output_vector_size(const gfdm_oracle_tx* t);
+/* transmitter_kernel::modulate + add_frame for cyclic_shifts[port]; in: nblocks x ninput_size symbols, out: nblocks x output_vector_size */
+void gfdm_oracle_tx_work(gfdm_oracle_tx* t, float* out, const float* in, int ninput_size, long nblocks, int port);
+
 #ifdef __cplusplus
 }
 #endif

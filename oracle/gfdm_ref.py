@@ -189,3 +189,47 @@ def advanced_receive(frame, ntaps, M, K, L, smap, points, ic_iter, f_eq=None,
         stages["dec_margin"] = None
         return out, stages
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Composite transmitter: resource mapper -> modulator -> cyclic prefix + ramp -> preamble
+
+def map_to_resources(symbols, M, K, smap, per_timeslot=True):
+    """resource_mapper_kernel_cc::map_to_resources -- lib/resource_mapper_kernel_cc.cc:74-89, 108-134.
+    symbols: (..., n) with n <= len(smap)*M; output (..., K*M) subcarrier-major, zero elsewhere.
+    The reference walks the SORTED subcarrier map (constructor sorts it, :55)."""
+    s = _c128(symbols)
+    batch = s.shape[:-1]
+    smap = np.sort(np.asarray(smap, dtype=np.int64))
+    A = len(smap)
+    full = np.zeros(batch + (A * M,), dtype=np.complex128)
+    full[..., :s.shape[-1]] = s
+    grid = np.zeros(batch + (K, M), dtype=np.complex128)
+    if per_timeslot:
+        grid[..., smap, :] = np.swapaxes(full.reshape(batch + (M, A)), -1, -2)     # symbol t*A + a -> (smap[a], t)
+    else:
+        grid[..., smap, :] = full.reshape(batch + (A, M))                          # symbol a*M + t -> (smap[a], t)
+    return grid.reshape(batch + (K * M,))
+
+
+def add_cyclic_prefix(block, cp_len, cs_len, ramp_len, window_taps, cyclic_shift=0):
+    """add_cyclic_prefix_cc::add_cyclic_prefix -- lib/add_cyclic_prefix_cc.cc:66-98.  window_taps has either the whole
+    window (block+cp+cs) or just 2*ramp_len taps; only its first and last ramp_len entries are used (:51-56)."""
+    x = _c128(block)
+    N = x.shape[-1]
+    w = _c128(window_taps)
+    cp_start = N - cp_len - cyclic_shift
+    out = np.concatenate((x[..., cp_start:], x, x[..., :cs_len - cyclic_shift]), axis=-1)
+    if ramp_len > 0:
+        out = out.copy()
+        out[..., :ramp_len] *= w[:ramp_len]
+        out[..., out.shape[-1] - ramp_len:] *= w[len(w) - ramp_len:]
+    return out
+
+
+def transmit(symbols, ntaps, M, K, L, smap, per_timeslot, cp_len, cs_len, ramp_len, window_taps, cyclic_shift, preamble):
+    """transmitter_kernel::modulate + add_frame -- lib/transmitter_kernel.cc:78-107 for one cyclic shift."""
+    block = modulate(map_to_resources(symbols, M, K, smap, per_timeslot), ntaps, M, K, L)
+    body = add_cyclic_prefix(block, cp_len, cs_len, ramp_len, window_taps, cyclic_shift)
+    pre = np.broadcast_to(_c128(preamble), body.shape[:-1] + (len(preamble),))
+    return np.concatenate((pre, body), axis=-1)

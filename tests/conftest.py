@@ -24,7 +24,22 @@ def pytest_configure(config):
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """kernel-path fixtures (make_golden.py); the composite-transmitter fixtures (make_golden_tx.py) are tx_*"""
+    names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return [n for n in names if not n.startswith("tx_")]
+
+
+def tx_golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "tx_*.npz")))
+
+
+def load_tx_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    for k in ("M", "K", "A", "L", "cp", "cs", "ramp"):
+        g[k] = int(g[k])
+    g["per_timeslot"] = bool(g["per_timeslot"])
+    return g
 
 
 def load_golden(name):
