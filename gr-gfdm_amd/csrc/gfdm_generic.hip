@@ -14,6 +14,7 @@
 //   receiver   lib/receiver_kernel_cc.cc:165-192, 211-225, 274-334
 //   IC loop    lib/advanced_receiver_kernel_cc.cc:56-123
 #include "gfdm_plan.h"
+#include "gfdm_tx.h"
 
 namespace gfdm {
 namespace {
@@ -134,16 +135,20 @@ __device__ void cancel_rows(cf* dst, const cf* td, const cf* fd, const DevicePla
     }
 }
 
-__global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan p, cf* __restrict__ out, const cf* __restrict__ in)
+__global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan p, TxParams tx, cf* __restrict__ out, const cf* __restrict__ in)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* t0 = reinterpret_cast<cf*>(smem);
     cf* t1 = t0 + p.N;
     const int M = p.M, K = p.K, L = p.L, N = p.N;
-    const cf* x = in + (int64_t)blockIdx.x * N;
+    const cf* x = in + (int64_t)blockIdx.x * (tx.mapped ? tx.nin : N);
     cf* o = out + (int64_t)blockIdx.x * N;
 
-    for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
+    if (tx.mapped) {                                               // resource mapper fused into the load (gfdm_tx.h)
+        for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = tx_symbol(tx, x, M, idx / M, idx % M);
+    } else {
+        for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
+    }
     __syncthreads();
     row_dft<false>(t0, t1, K, M, M, 1, p.wM, 1.f);                 // D_k = FFT_M(d_k)                 :109-110
     __syncthreads();
@@ -179,8 +184,19 @@ __global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan p, cf* __res
             e += pp;
             if (e >= M) e -= M;
         }
-        o[idx] = make_float2(acc.x * scale, acc.y * scale);
+        const cf y = make_float2(acc.x * scale, acc.y * scale);
+        if (tx.framed) tx_store_sample(tx, blockIdx.x, N, idx, y);      // cyclic prefix / suffix + ramp, every port
+        else o[idx] = y;
     }
+    if (tx.framed) tx_store_preamble(tx, blockIdx.x, threadIdx.x, GT);
+}
+
+// transmitter_kernel::add_frame on an already modulated block
+__global__ __launch_bounds__(GT) void k_add_frame(DevicePlan p, TxParams tx, const cf* __restrict__ in)
+{
+    const cf* x = in + (int64_t)blockIdx.x * p.N;
+    for (int idx = threadIdx.x; idx < p.N; idx += GT) tx_store_sample(tx, blockIdx.x, p.N, idx, x[idx]);
+    tx_store_preamble(tx, blockIdx.x, threadIdx.x, GT);
 }
 
 __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams ic, int mode, int s_in_global, cf* __restrict__ out,
@@ -315,13 +331,20 @@ size_t generic_lds_bytes(int N, int ntiles) { return (size_t)ntiles * (size_t)N 
 
 bool generic_supports(int N, bool) { return generic_lds_bytes(N, 2) <= LDS_MAX; }
 
-hipError_t launch_generic_modulate(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
+hipError_t launch_generic_modulate(const DevicePlan& p, const TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
     const size_t lds = generic_lds_bytes(p.N, 2);
     hipError_t e = allow_lds(k_generic_modulate, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_generic_modulate, dim3((unsigned)nblocks), dim3(GT), lds, s, p, out, in);
+    hipLaunchKernelGGL(k_generic_modulate, dim3((unsigned)nblocks), dim3(GT), lds, s, p, tx, out, in);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_frame(const DevicePlan& p, const TxParams& tx, const cf* in, int64_t nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add_frame, dim3((unsigned)nblocks), dim3(GT), 0, s, p, tx, in);
     return hipGetLastError();
 }
 

@@ -3,11 +3,14 @@
 // device or a kernel launch is unavailable the call fails with an error code.
 #include "../../include/gfdm_hip.h"
 #include "gfdm_plan.h"
+#include "gfdm_tx.h"
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -244,12 +247,14 @@ hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, cons
     return gfdm::launch_generic_receive(pl.dp, ic, mode, out, in, f_eq, nblocks, s);
 }
 
-hipError_t mod_launch(Plan& pl, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
+hipError_t mod_launch(Plan& pl, const gfdm::TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
-    if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_modulate(pl.dp, pl.d_twT, out, in, nblocks, s);
-    if (pl.family == gfdm::FAMILY_FAST) return gfdm::launch_fast_modulate(pl.dp, pl.d_twT, out, in, nblocks, s);
-    return gfdm::launch_generic_modulate(pl.dp, out, in, nblocks, s);
+    if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_modulate(pl.dp, tx, pl.d_twT, out, in, nblocks, s);
+    if (pl.family == gfdm::FAMILY_FAST && !tx.mapped && !tx.framed) return gfdm::launch_fast_modulate(pl.dp, pl.d_twT, out, in, nblocks, s);
+    return gfdm::launch_generic_modulate(pl.dp, tx, out, in, nblocks, s);
 }
+
+const gfdm::TxParams kNoTx = {};
 
 const gfdm::IcParams kNoIc = { 0, 0, 0, 0, nullptr, nullptr, 0, nullptr };
 
@@ -331,7 +336,7 @@ int gfdm_hip_modulator_work_device(gfdm_hip_modulator* m, void* out, const void*
 {
     if (!m) return fail(GFDM_HIP_EINVAL, "NULL handle");
     return run_device(m->plan, out, in, nblocks, [&]() {
-        return mod_launch(m->plan, (cf*)out, (const cf*)in, nblocks, (hipStream_t)stream);
+        return mod_launch(m->plan, kNoTx, (cf*)out, (const cf*)in, nblocks, (hipStream_t)stream);
     });
 }
 
@@ -339,7 +344,7 @@ int gfdm_hip_modulator_work_host(gfdm_hip_modulator* m, float* out, const float*
 {
     if (!m) return fail(GFDM_HIP_EINVAL, "NULL handle");
     return run_host(m->plan, out, in, nullptr, nblocks, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
-        return mod_launch(m->plan, o, i, nblocks, s);
+        return mod_launch(m->plan, kNoTx, o, i, nblocks, s);
     });
 }
 
@@ -547,6 +552,222 @@ int gfdm_hip_advanced_receiver_work_host(gfdm_hip_advanced_receiver* a, float* o
     if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
     return run_host(a->plan, out, in, f_eq, nblocks, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
         return rx_launch(a->plan, a->ic, gfdm::RX_IC, o, i, e, nblocks, s);
+    });
+}
+
+}  // extern "C"
+
+// ---- composite transmitter (gr-gfdm transmitter_kernel) ----
+
+struct gfdm_hip_transmitter {
+    Plan plan;
+    gfdm::TxParams tx{};          // template: device tables, lengths, shifts; per call: outs, nin, mapped/framed
+    void* d_blob = nullptr;       // rank | front | back | preambles
+    cf* stage_out = nullptr;      // staging of the *_host frame outputs
+    size_t stage_out_elems = 0;
+    int M = 0, K = 0, A = 0;
+    ~gfdm_hip_transmitter()
+    {
+        DeviceGuard guard(plan.device);
+        if (d_blob) (void)hipFree(d_blob);
+        if (stage_out) (void)hipFree(stage_out);
+    }
+};
+
+extern "C" {
+
+int gfdm_hip_transmitter_create(gfdm_hip_transmitter** out, int timeslots, int subcarriers, int active_subcarriers, int cp_len,
+                                int cs_len, int ramp_len, const int* subcarrier_map, int n_subcarrier_map, int per_timeslot, int overlap,
+                                const float* taps, int ntaps, const float* window_taps, int n_window_taps, const int* cyclic_shifts,
+                                int n_cyclic_shifts, const float* preambles, int preamble_len, int device)
+{
+    if (!out) return fail(GFDM_HIP_EINVAL, "NULL handle pointer");
+    *out = nullptr;
+    const int M = timeslots, K = subcarriers, A = active_subcarriers;
+    char buf[256];
+    // resource_mapper_kernel_cc constructor checks, lib/resource_mapper_kernel_cc.cc:44-69
+    if (M < 1 || K < 1 || A < 1) return fail(GFDM_HIP_EINVAL, "timeslots, subcarriers and active_subcarriers must be >= 1");
+    if (A > K) {
+        snprintf(buf, sizeof(buf), "active_subcarriers(%d) MUST be smaller or equal to subcarriers(%d)!", A, K);
+        return fail(GFDM_HIP_EINVAL, buf);
+    }
+    if (!subcarrier_map || n_subcarrier_map != A) {
+        snprintf(buf, sizeof(buf), "number of subcarrier_map entries(%d) MUST be equal to active_subcarriers(%d)!", n_subcarrier_map, A);
+        return fail(GFDM_HIP_EINVAL, buf);
+    }
+    std::vector<int> smap(subcarrier_map, subcarrier_map + A);
+    std::sort(smap.begin(), smap.end());
+    if (std::adjacent_find(smap.begin(), smap.end()) != smap.end()) return fail(GFDM_HIP_EINVAL, "All entries in subcarrier_map MUST be unique!");
+    if (smap.front() < 0) return fail(GFDM_HIP_EINVAL, "All subcarrier indices MUST be greater or equal to ZERO!");
+    if (smap.back() >= K) return fail(GFDM_HIP_EINVAL, "All subcarrier indices MUST be smaller than subcarriers!");
+    // add_cyclic_prefix_cc constructor check, lib/add_cyclic_prefix_cc.cc:42-50
+    const int N = M * K, window_len = N + cp_len + cs_len;
+    if (cp_len < 0 || cs_len < 0 || ramp_len < 0 || !window_taps || (n_window_taps != window_len && n_window_taps != 2 * ramp_len)) {
+        snprintf(buf, sizeof(buf), "number of window taps(%d) MUST be equal to 2*ramp_len(%d) OR block_len+cp_len (%d)!", n_window_taps,
+                 2 * ramp_len, window_len);
+        return fail(GFDM_HIP_EINVAL, buf);
+    }
+    if (2 * ramp_len > window_len) return fail(GFDM_HIP_EINVAL, "ramp_len too large for the frame");
+    // transmitter_kernel constructor checks, lib/transmitter_kernel.cc:57-67 (the C-ABI takes preambles as one [n][len] array)
+    if (n_cyclic_shifts < 1 || n_cyclic_shifts > gfdm::TX_MAX_PORTS || !cyclic_shifts)
+        return fail(GFDM_HIP_EINVAL, "Number of cyclic shifts and number of preambles do not match!");
+    if (preamble_len < 0 || (preamble_len > 0 && !preambles)) return fail(GFDM_HIP_EINVAL, "All preambles must have equal size!");
+    for (int i = 0; i < n_cyclic_shifts; ++i)
+        if (cyclic_shifts[i] < 0 || cyclic_shifts[i] > cs_len || cp_len + cyclic_shifts[i] > N)
+            return fail(GFDM_HIP_EINVAL, "cyclic shift must lie in [0, cs_len] and cp_len + shift must not exceed the block");
+
+    gfdm_hip_transmitter* t = new (std::nothrow) gfdm_hip_transmitter();
+    if (!t) return fail(GFDM_HIP_ENOMEM, "out of host memory");
+    int rc = plan_create(t->plan, M, K, overlap, taps, ntaps, device, false);
+    if (rc != GFDM_HIP_OK) { delete t; return rc; }
+    t->M = M; t->K = K; t->A = A;
+
+    const size_t rank_bytes = ((size_t)K * sizeof(short) + 15) / 16 * 16;
+    const size_t ramp_bytes = (size_t)(ramp_len > 0 ? ramp_len : 1) * sizeof(cf);
+    const size_t pre_bytes = (size_t)n_cyclic_shifts * (size_t)(preamble_len > 0 ? preamble_len : 1) * sizeof(cf);
+    std::vector<unsigned char> blob(rank_bytes + 2 * ramp_bytes + pre_bytes, 0);
+    short* rank = reinterpret_cast<short*>(blob.data());
+    for (int k = 0; k < K; ++k) rank[k] = -1;
+    for (int a = 0; a < A; ++a) rank[smap[a]] = (short)a;
+    const cf* w = reinterpret_cast<const cf*>(window_taps);
+    memcpy(blob.data() + rank_bytes, w, (size_t)ramp_len * sizeof(cf));                                     // front ramp  :51-53
+    memcpy(blob.data() + rank_bytes + ramp_bytes, w + (n_window_taps - ramp_len), (size_t)ramp_len * sizeof(cf));   // back ramp :54-56
+    if (preamble_len > 0) memcpy(blob.data() + rank_bytes + 2 * ramp_bytes, preambles, (size_t)n_cyclic_shifts * preamble_len * sizeof(cf));
+    {
+        DeviceGuard guard(device);
+        hipError_t e = hipMalloc(&t->d_blob, blob.size());
+        if (e == hipSuccess) e = hipMemcpy(t->d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { delete t; return fail_hip(e, "transmitter table upload"); }
+    }
+    gfdm::TxParams& tx = t->tx;
+    tx.A = A; tx.per_timeslot = per_timeslot ? 1 : 0; tx.nin = A * M;
+    tx.cp = cp_len; tx.cs = cs_len; tx.ramp = ramp_len; tx.plen = preamble_len; tx.F = preamble_len + window_len;
+    tx.nports = n_cyclic_shifts;
+    for (int i = 0; i < n_cyclic_shifts; ++i) tx.shifts[i] = cyclic_shifts[i];
+    unsigned char* d = reinterpret_cast<unsigned char*>(t->d_blob);
+    tx.rank = reinterpret_cast<const short*>(d);
+    tx.front = reinterpret_cast<const cf*>(d + rank_bytes);
+    tx.back = reinterpret_cast<const cf*>(d + rank_bytes + ramp_bytes);
+    tx.preambles = reinterpret_cast<const cf*>(d + rank_bytes + 2 * ramp_bytes);
+    *out = t;
+    return GFDM_HIP_OK;
+}
+
+int gfdm_hip_transmitter_destroy(gfdm_hip_transmitter* t) { delete t; return GFDM_HIP_OK; }
+int gfdm_hip_transmitter_input_vector_size(const gfdm_hip_transmitter* t) { return t ? t->A * t->M : GFDM_HIP_EINVAL; }
+int gfdm_hip_transmitter_output_vector_size(const gfdm_hip_transmitter* t) { return t ? t->tx.F : GFDM_HIP_EINVAL; }
+int gfdm_hip_transmitter_block_size(const gfdm_hip_transmitter* t) { return t ? t->plan.dp.N : GFDM_HIP_EINVAL; }
+int gfdm_hip_transmitter_n_cyclic_shifts(const gfdm_hip_transmitter* t) { return t ? t->tx.nports : GFDM_HIP_EINVAL; }
+int gfdm_hip_transmitter_cyclic_shift(const gfdm_hip_transmitter* t, int port)
+{
+    return (t && port >= 0 && port < t->tx.nports) ? t->tx.shifts[port] : GFDM_HIP_EINVAL;
+}
+const char* gfdm_hip_transmitter_kernel_name(const gfdm_hip_transmitter* t) { return t ? t->plan.kernel_name.c_str() : ""; }
+
+static int tx_check_nin(const gfdm_hip_transmitter* t, int ninput_size)
+{
+    if (ninput_size < 0 || ninput_size > t->A * t->M) {
+        char buf[200];
+        snprintf(buf, sizeof(buf), "input vector size(%d) MUST not exceed active_subcarriers * timeslots(%d)!", ninput_size, t->A * t->M);
+        return fail(GFDM_HIP_EINVAL, buf);                 // std::invalid_argument in resource_mapper_kernel_cc.cc:78-82
+    }
+    return GFDM_HIP_OK;
+}
+
+int gfdm_hip_transmitter_work_device(gfdm_hip_transmitter* t, void* const* outs, int n_outs, const void* in, int ninput_size,
+                                     int64_t nblocks, void* stream)
+{
+    if (!t || !outs || !in) return fail(GFDM_HIP_EINVAL, "NULL argument");
+    if (n_outs < 1 || n_outs > t->tx.nports) return fail(GFDM_HIP_EINVAL, "n_outs must be between 1 and the number of cyclic shifts");
+    int rc = tx_check_nin(t, ninput_size);
+    if (rc != GFDM_HIP_OK) return rc;
+    gfdm::TxParams tx = t->tx;
+    tx.mapped = 1; tx.framed = 1; tx.nin = ninput_size; tx.nports = n_outs;
+    for (int i = 0; i < n_outs; ++i) {
+        if (!outs[i]) return fail(GFDM_HIP_EINVAL, "NULL output port");
+        tx.outs[i] = (cf*)outs[i];
+    }
+    return run_device(t->plan, outs[0], in, nblocks, [&]() { return mod_launch(t->plan, tx, nullptr, (const cf*)in, nblocks, (hipStream_t)stream); });
+}
+
+int gfdm_hip_transmitter_modulate_device(gfdm_hip_transmitter* t, void* out, const void* in, int ninput_size, int64_t nblocks, void* stream)
+{
+    if (!t) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    int rc = tx_check_nin(t, ninput_size);
+    if (rc != GFDM_HIP_OK) return rc;
+    gfdm::TxParams tx = t->tx;
+    tx.mapped = 1; tx.framed = 0; tx.nin = ninput_size;
+    return run_device(t->plan, out, in, nblocks, [&]() { return mod_launch(t->plan, tx, (cf*)out, (const cf*)in, nblocks, (hipStream_t)stream); });
+}
+
+int gfdm_hip_transmitter_add_frame_device(gfdm_hip_transmitter* t, void* out, const void* in, int cyclic_shift, int64_t nblocks, void* stream)
+{
+    if (!t) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    int port = -1;
+    for (int i = 0; i < t->tx.nports; ++i) if (t->tx.shifts[i] == cyclic_shift) { port = i; break; }
+    if (port < 0) return fail(GFDM_HIP_EINVAL, "no preamble was registered for this cyclic shift");     // d_preambles lookup, transmitter_kernel.cc:86-90
+    gfdm::TxParams tx = t->tx;
+    tx.mapped = 0; tx.framed = 1; tx.nports = 1; tx.shifts[0] = cyclic_shift; tx.outs[0] = (cf*)out;
+    tx.preambles = t->tx.preambles + (int64_t)port * t->tx.plen;
+    return run_device(t->plan, out, in, nblocks, [&]() { return gfdm::launch_add_frame(t->plan.dp, tx, (const cf*)in, nblocks, (hipStream_t)stream); });
+}
+
+// host-pointer variants: stage, launch, copy back
+static int tx_host(gfdm_hip_transmitter* t, float* const* outs, int n_outs, size_t out_elems_per_block, const float* in,
+                   size_t in_elems_per_block, int64_t nblocks, const std::function<int(void* const*, const void*, hipStream_t)>& enqueue)
+{
+    if (nblocks < 0 || !outs || !in) return fail(GFDM_HIP_EINVAL, "NULL buffer or negative block count");
+    if (nblocks == 0) return GFDM_HIP_OK;
+    Plan& pl = t->plan;
+    DeviceGuard guard(pl.device);
+    if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
+    const size_t in_elems = (size_t)nblocks * in_elems_per_block, out_elems = (size_t)nblocks * out_elems_per_block;
+    int rc = ensure_stage(pl, 1, in_elems > 0 ? in_elems : 1);
+    if (rc != GFDM_HIP_OK) return rc;
+    if (t->stage_out_elems < out_elems * n_outs) {
+        if (t->stage_out) (void)hipFree(t->stage_out);
+        t->stage_out = nullptr; t->stage_out_elems = 0;
+        if (hipMalloc(&t->stage_out, out_elems * n_outs * sizeof(cf)) != hipSuccess) return fail(GFDM_HIP_ENOMEM, "device staging buffer allocation failed");
+        t->stage_out_elems = out_elems * n_outs;
+    }
+    HIP_TRY(hipMemcpyAsync(pl.stage[1], in, in_elems * sizeof(cf), hipMemcpyHostToDevice, pl.stream));
+    void* dev_outs[gfdm::TX_MAX_PORTS];
+    for (int i = 0; i < n_outs; ++i) dev_outs[i] = t->stage_out + (size_t)i * out_elems;
+    rc = enqueue(dev_outs, pl.stage[1], pl.stream);
+    if (rc != GFDM_HIP_OK) return rc;
+    for (int i = 0; i < n_outs; ++i) HIP_TRY(hipMemcpyAsync(outs[i], dev_outs[i], out_elems * sizeof(cf), hipMemcpyDeviceToHost, pl.stream));
+    HIP_TRY(hipStreamSynchronize(pl.stream));
+    return GFDM_HIP_OK;
+}
+
+int gfdm_hip_transmitter_work_host(gfdm_hip_transmitter* t, float* const* outs, int n_outs, const float* in, int ninput_size, int64_t nblocks)
+{
+    if (!t) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    if (n_outs < 1 || n_outs > t->tx.nports) return fail(GFDM_HIP_EINVAL, "n_outs must be between 1 and the number of cyclic shifts");
+    int rc = tx_check_nin(t, ninput_size);
+    if (rc != GFDM_HIP_OK) return rc;
+    return tx_host(t, outs, n_outs, (size_t)t->tx.F, in, (size_t)ninput_size, nblocks, [&](void* const* d_outs, const void* d_in, hipStream_t s) {
+        return gfdm_hip_transmitter_work_device(t, d_outs, n_outs, d_in, ninput_size, nblocks, (void*)s);
+    });
+}
+
+int gfdm_hip_transmitter_modulate_host(gfdm_hip_transmitter* t, float* out, const float* in, int ninput_size, int64_t nblocks)
+{
+    if (!t) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    int rc = tx_check_nin(t, ninput_size);
+    if (rc != GFDM_HIP_OK) return rc;
+    float* outs[1] = { out };
+    return tx_host(t, outs, 1, (size_t)t->plan.dp.N, in, (size_t)ninput_size, nblocks, [&](void* const* d_outs, const void* d_in, hipStream_t s) {
+        return gfdm_hip_transmitter_modulate_device(t, d_outs[0], d_in, ninput_size, nblocks, (void*)s);
+    });
+}
+
+int gfdm_hip_transmitter_add_frame_host(gfdm_hip_transmitter* t, float* out, const float* in, int cyclic_shift, int64_t nblocks)
+{
+    if (!t) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    float* outs[1] = { out };
+    return tx_host(t, outs, 1, (size_t)t->tx.F, in, (size_t)t->plan.dp.N, nblocks, [&](void* const* d_outs, const void* d_in, hipStream_t s) {
+        return gfdm_hip_transmitter_add_frame_device(t, d_outs[0], d_in, cyclic_shift, nblocks, (void*)s);
     });
 }
 

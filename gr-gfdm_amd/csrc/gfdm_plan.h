@@ -46,7 +46,10 @@ enum RxMode {
 
 // ---- generic family (any M, K, L; one workgroup per block, everything staged in LDS) ----
 size_t generic_lds_bytes(int N, int ntiles);
-hipError_t launch_generic_modulate(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+struct TxParams;   // gfdm_tx.h: resource mapper in front of / cyclic prefix + preamble behind the modulator
+hipError_t launch_generic_modulate(const DevicePlan& p, const TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+// transmitter_kernel::add_frame: preamble + cyclic prefix/suffix + ramp of already modulated blocks, port 0 of tx
+hipError_t launch_add_frame(const DevicePlan& p, const TxParams& tx, const cf* in, int64_t nblocks, hipStream_t s);
 hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq,
                                   int64_t nblocks, hipStream_t s);
 hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
@@ -62,7 +65,8 @@ hipError_t launch_fast_receive(const DevicePlan& p, const IcParams& ic, const cf
 
 // ---- row-lane family (gfdm_rowlane.hip): one lane per subcarrier row, LDS ping-pong radix-4 passes ----
 bool rowlane_supports(int M, int K, int L);
-hipError_t launch_rowlane_modulate(const DevicePlan& p, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+hipError_t launch_rowlane_modulate(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks,
+                                   hipStream_t s);
 hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in,
                                   const cf* f_eq, int64_t nblocks, hipStream_t s);
 

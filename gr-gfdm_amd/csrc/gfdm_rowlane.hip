@@ -22,6 +22,7 @@
 // lib/advanced_receiver_kernel_cc.cc:56-123.
 #include "gfdm_dft.h"
 #include "gfdm_plan.h"
+#include "gfdm_tx.h"
 
 #include <cstdlib>
 
@@ -374,9 +375,12 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
 }
 
 // =====================================================================================================================
-template <int K, int M, int L>
-__global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, const cf* __restrict__ twT, cf* __restrict__ out,
-                                                                 const cf* __restrict__ in, int64_t nblocks)
+// TXMODE 0: plain modulator.  1: input through the resource mapper (transmitter_kernel::modulate).
+// 2: mapper in front AND cyclic prefix / suffix + ramp + preamble behind, all ports (transmitter_kernel::generic_work for every
+// cyclic shift of the reference's transmitter_cc_impl::general_work, lib/transmitter_cc_impl.cc:165-177) -- see gfdm_tx.h.
+template <int K, int M, int L, int TXMODE>
+__global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, TxParams tx, const cf* __restrict__ twT,
+                                                                 cf* __restrict__ out, const cf* __restrict__ in, int64_t nblocks)
 {
     using S = RowShape<K>;
     using T = RowTile<K, M>;
@@ -389,11 +393,18 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
     const int64_t base = (valid ? blk : 0) * N;
     cf* X = reinterpret_cast<cf*>(smem) + g * T::TS;
 
-    // symbols [k][p], copied linearly (coalesced) into the tile; lane k then owns row k
-    static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; X[q + K * i] = in[base + q + K * i]; });
-    block_sync<K>();
     cf v[M];
-    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = X[q * M + m]; });
+    if constexpr (TXMODE == 0) {
+        // symbols [k][p], copied linearly (coalesced) into the tile; lane k then owns row k
+        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; X[q + K * i] = in[base + q + K * i]; });
+        block_sync<K>();
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = X[q * M + m]; });
+    } else {
+        // resource mapper fused into the load: lane k gathers its own subcarrier's symbols (for per-timeslot order the lanes
+        // of one timeslot read consecutive input symbols)
+        const cf* sym = in + (valid ? blk : 0) * (int64_t)tx.nin;
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = tx_symbol(tx, sym, M, q, m); });
+    }
     dft_inplace<M, false>(v);                                                                          // mod:109-110
     // gather form of filter + overlap-add: Y[j][m] = sum_i D[(j - i + L/2) mod K][m] taps[((i + L/2) % L) M + m]   mod:116-132
     constexpr float invN = 1.0f / (float)N;
@@ -433,7 +444,12 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
     static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = cmulc(X[q * M + m], twT[m * K + q]); });
     dft_inplace<M, true>(v);                                                                           // mod:137-140
     if (valid) {
-        static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; out[base + K * pp + q] = v[pp]; });
+        if constexpr (TXMODE == 2) {
+            static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; tx_store_sample(tx, blk, N, K * pp + q, v[pp]); });
+            tx_store_preamble(tx, blk, q, K);
+        } else {
+            static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; out[base + K * pp + q] = v[pp]; });
+        }
     }
 }
 
@@ -456,11 +472,13 @@ hipError_t launch_rx(const DevicePlan& p, const IcParams& ic, const cf* twT, int
 }
 
 template <int K, int M, int L>
-hipError_t launch_mod(const DevicePlan& p, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t st)
+hipError_t launch_mod(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t st)
 {
     constexpr size_t lds = row_lds_bytes<K, M>();
     const dim3 grid((unsigned)((nblocks + RowShape<K>::BPW - 1) / RowShape<K>::BPW)), block(RowShape<K>::WG);
-    hipLaunchKernelGGL((k_row_modulate<K, M, L>), grid, block, lds, st, p, twT, out, in, nblocks);
+    if (tx.mapped && tx.framed) hipLaunchKernelGGL((k_row_modulate<K, M, L, 2>), grid, block, lds, st, p, tx, twT, out, in, nblocks);
+    else if (tx.mapped) hipLaunchKernelGGL((k_row_modulate<K, M, L, 1>), grid, block, lds, st, p, tx, twT, out, in, nblocks);
+    else hipLaunchKernelGGL((k_row_modulate<K, M, L, 0>), grid, block, lds, st, p, tx, twT, out, in, nblocks);
     return hipGetLastError();
 }
 
@@ -485,10 +503,11 @@ bool rowlane_supports(int M, int K, int L)
     return false;
 }
 
-hipError_t launch_rowlane_modulate(const DevicePlan& p, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
+hipError_t launch_rowlane_modulate(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks,
+                                   hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-#define X(K_, M_, L_) if (p.K == K_ && p.M == M_ && p.L == L_) return launch_mod<K_, M_, L_>(p, twT, out, in, nblocks, s);
+#define X(K_, M_, L_) if (p.K == K_ && p.M == M_ && p.L == L_) return launch_mod<K_, M_, L_>(p, tx, twT, out, in, nblocks, s);
     GFDM_ROW_SHAPES(X)
 #undef X
     return hipErrorInvalidValue;

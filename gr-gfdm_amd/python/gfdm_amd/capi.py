@@ -75,6 +75,20 @@ def lib():
         "gfdm_hip_advanced_receiver_kernel_name": (cp, [vp]),
         "gfdm_hip_advanced_receiver_work_host": (i32, [vp, vp, vp, vp, i64]),
         "gfdm_hip_advanced_receiver_work_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_transmitter_create": (i32, [ctypes.POINTER(vp)] + [i32] * 6 + [vp, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32]),
+        "gfdm_hip_transmitter_destroy": (i32, [vp]),
+        "gfdm_hip_transmitter_input_vector_size": (i32, [vp]),
+        "gfdm_hip_transmitter_output_vector_size": (i32, [vp]),
+        "gfdm_hip_transmitter_block_size": (i32, [vp]),
+        "gfdm_hip_transmitter_n_cyclic_shifts": (i32, [vp]),
+        "gfdm_hip_transmitter_cyclic_shift": (i32, [vp, i32]),
+        "gfdm_hip_transmitter_kernel_name": (cp, [vp]),
+        "gfdm_hip_transmitter_work_host": (i32, [vp, vp, i32, vp, i32, i64]),
+        "gfdm_hip_transmitter_work_device": (i32, [vp, vp, i32, vp, i32, i64, vp]),
+        "gfdm_hip_transmitter_modulate_host": (i32, [vp, vp, vp, i32, i64]),
+        "gfdm_hip_transmitter_modulate_device": (i32, [vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_transmitter_add_frame_host": (i32, [vp, vp, vp, i32, i64]),
+        "gfdm_hip_transmitter_add_frame_device": (i32, [vp, vp, vp, i32, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == the library does not export a declared symbol
@@ -94,7 +108,7 @@ def _check(status):
         return
     L = lib()
     msg = (L.gfdm_hip_last_error() or b"").decode() or L.gfdm_hip_strerror(status).decode()
-    if status in (EINVAL_TAPS, EINVAL_OVERLAP):
+    if status in (EINVAL_TAPS, EINVAL_OVERLAP, EINVAL):
         raise ValueError(msg)            # std::invalid_argument in the reference (pybind11 maps it to ValueError)
     raise GfdmHipError(status, msg)
 
@@ -324,3 +338,102 @@ class AdvancedReceiver(_Kernel):
     def demodulate_equalize(self, x, f_eq, out=None, stream=None):
         """generic_work_equalize: one f_eq vector per block."""
         return self._call(x, f_eq, out, stream)
+
+
+class Transmitter(_Kernel):
+    """gr::gfdm::transmitter_kernel (include/gfdm/transmitter_kernel.h:43-85) on the GPU: resource mapper -> modulator ->
+    cyclic prefix/suffix with cyclic shift + window ramp -> preamble as ONE kernel, every cyclic shift ("port") at once."""
+    _destroy = "gfdm_hip_transmitter_destroy"
+
+    def __init__(self, timeslots, subcarriers, active_subcarriers, cp_len, cs_len, ramp_len, subcarrier_map, per_timeslot, overlap,
+                 frequency_taps, window_taps, cyclic_shifts, preambles, device=0):
+        L = lib()
+        t, tp, tn = _taps_arg(frequency_taps)
+        w = _c64(np.asarray(window_taps).ravel())
+        smap = np.ascontiguousarray(subcarrier_map, dtype=np.int32)
+        shifts = np.ascontiguousarray(cyclic_shifts, dtype=np.int32)
+        pre = [np.asarray(p).ravel() for p in preambles]
+        if len(pre) != shifts.size:
+            raise ValueError("Number of cyclic shifts and number of preambles do not match!")
+        if any(p.size != pre[0].size for p in pre):
+            raise ValueError("All preambles must have equal size!")
+        pre = _c64(np.stack(pre)) if pre else np.zeros((0, 0), np.complex64)
+        h = ctypes.c_void_p()
+        _check(L.gfdm_hip_transmitter_create(ctypes.byref(h), timeslots, subcarriers, active_subcarriers, cp_len, cs_len, ramp_len,
+                                             smap.ctypes.data, smap.size, int(bool(per_timeslot)), overlap, tp, tn, w.ctypes.data, w.size,
+                                             shifts.ctypes.data, shifts.size, pre.ctypes.data, pre.shape[1] if pre.size else 0, device))
+        self._h = h
+        self._shifts = [int(x) for x in shifts]
+
+    def input_vector_size(self):
+        return lib().gfdm_hip_transmitter_input_vector_size(self._h)
+
+    def output_vector_size(self):
+        return lib().gfdm_hip_transmitter_output_vector_size(self._h)
+
+    def block_size(self):
+        return lib().gfdm_hip_transmitter_block_size(self._h)
+
+    def cyclic_shifts(self):
+        return list(self._shifts)
+
+    def kernel_name(self):
+        return lib().gfdm_hip_transmitter_kernel_name(self._h).decode()
+
+    def _split(self, x, ninput_size):
+        n = self.input_vector_size() if ninput_size is None else int(ninput_size)
+        size = x.numel() if _is_tensor(x) else np.asarray(x).size
+        if n <= 0 or size % n:
+            raise RuntimeError("input size(%d) MUST be a multiple of ninput_size(%d)!" % (size, n))
+        return n, size // n
+
+    def transmit(self, symbols, ninput_size=None, n_ports=None, stream=None):
+        """All ports (or the first n_ports): list of (nblocks, output_vector_size) arrays / tensors, one per cyclic shift."""
+        L = lib()
+        n, nb = self._split(symbols, ninput_size)
+        ports = len(self._shifts) if n_ports is None else n_ports
+        F = self.output_vector_size()
+        if _is_tensor(symbols):
+            import torch
+            outs = [torch.empty(nb, F, dtype=torch.complex64, device=symbols.device) for _ in range(ports)]
+            arr = (ctypes.c_void_p * ports)(*[o.data_ptr() for o in outs])
+            _check(L.gfdm_hip_transmitter_work_device(self._h, arr, ports, _dev_ptr(symbols, nb * n, "in"), n, nb, _stream_ptr(stream)))
+            return outs
+        x = _c64(symbols)
+        outs = [np.empty((nb, F), np.complex64) for _ in range(ports)]
+        arr = (ctypes.c_void_p * ports)(*[o.ctypes.data for o in outs])
+        _check(L.gfdm_hip_transmitter_work_host(self._h, arr, ports, x.ctypes.data, n, nb))
+        return outs
+
+    def generic_work(self, symbols, ninput_size=None):
+        """transmitter_kernel::generic_work: the frame of cyclic_shifts[0]."""
+        return self.transmit(symbols, ninput_size, 1)[0]
+
+    def modulate(self, symbols, ninput_size=None, stream=None):
+        L = lib()
+        n, nb = self._split(symbols, ninput_size)
+        N = self.block_size()
+        if _is_tensor(symbols):
+            import torch
+            out = torch.empty(nb, N, dtype=torch.complex64, device=symbols.device)
+            _check(L.gfdm_hip_transmitter_modulate_device(self._h, out.data_ptr(), _dev_ptr(symbols, nb * n, "in"), n, nb, _stream_ptr(stream)))
+            return out
+        x = _c64(symbols)
+        out = np.empty((nb, N), np.complex64)
+        _check(L.gfdm_hip_transmitter_modulate_host(self._h, out.ctypes.data, x.ctypes.data, n, nb))
+        return out
+
+    def add_frame(self, blocks, cyclic_shift, stream=None):
+        L = lib()
+        N, F = self.block_size(), self.output_vector_size()
+        if _is_tensor(blocks):
+            import torch
+            nb = blocks.numel() // N
+            out = torch.empty(nb, F, dtype=torch.complex64, device=blocks.device)
+            _check(L.gfdm_hip_transmitter_add_frame_device(self._h, out.data_ptr(), _dev_ptr(blocks, nb * N, "in"), int(cyclic_shift), nb, _stream_ptr(stream)))
+            return out
+        x = _c64(blocks)
+        nb = x.size // N
+        out = np.empty((nb, F), np.complex64)
+        _check(L.gfdm_hip_transmitter_add_frame_host(self._h, out.ctypes.data, x.ctypes.data, int(cyclic_shift), nb))
+        return out

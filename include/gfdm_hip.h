@@ -125,6 +125,38 @@ const char* gfdm_hip_advanced_receiver_kernel_name(const gfdm_hip_advanced_recei
 int gfdm_hip_advanced_receiver_work_host(gfdm_hip_advanced_receiver* a, float* out, const float* in, const float* f_eq, int64_t nblocks);
 int gfdm_hip_advanced_receiver_work_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* f_eq, int64_t nblocks, void* stream);
 
+/* ---- transmitter_kernel (include/gfdm/transmitter_kernel.h:43-85) -------------
+ * resource mapper -> modulator -> cyclic prefix / suffix with cyclic shift + window ramp -> preamble, FUSED into one HIP kernel:
+ * the mapper is the modulator's load stage, prefix/suffix/ramp/preamble its store stage, for all cyclic shifts ("ports") at once. */
+typedef struct gfdm_hip_transmitter gfdm_hip_transmitter;
+
+/* ctor, lib/transmitter_kernel.cc:33-73 (which constructs resource_mapper_kernel_cc, modulator_kernel_cc, add_cyclic_prefix_cc).
+ * window_taps: n_window_taps complex (the whole window block+cp+cs, or 2*ramp_len); preambles: [n_cyclic_shifts][preamble_len] complex.
+ * Argument errors of the three reference constructors are reported as GFDM_HIP_EINVAL / GFDM_HIP_EINVAL_TAPS with their messages. */
+int gfdm_hip_transmitter_create(gfdm_hip_transmitter** out, int timeslots, int subcarriers, int active_subcarriers, int cp_len,
+                                int cs_len, int ramp_len, const int* subcarrier_map, int n_subcarrier_map, int per_timeslot, int overlap,
+                                const float* taps, int ntaps, const float* window_taps, int n_window_taps, const int* cyclic_shifts,
+                                int n_cyclic_shifts, const float* preambles, int preamble_len, int device);
+int gfdm_hip_transmitter_destroy(gfdm_hip_transmitter* t);
+int gfdm_hip_transmitter_input_vector_size(const gfdm_hip_transmitter* t);    /* .h:63, active_subcarriers * timeslots */
+int gfdm_hip_transmitter_output_vector_size(const gfdm_hip_transmitter* t);   /* .h:64, preamble + cp + block + cs */
+int gfdm_hip_transmitter_block_size(const gfdm_hip_transmitter* t);
+int gfdm_hip_transmitter_n_cyclic_shifts(const gfdm_hip_transmitter* t);
+int gfdm_hip_transmitter_cyclic_shift(const gfdm_hip_transmitter* t, int port); /* cyclic_shifts()[port], .h:69 */
+const char* gfdm_hip_transmitter_kernel_name(const gfdm_hip_transmitter* t);
+/* generic_work (lib/transmitter_kernel.cc:100-106) generalised to the first n_outs cyclic shifts, i.e. what
+ * transmitter_cc_impl::general_work does per frame (lib/transmitter_cc_impl.cc:165-177).  in: nblocks x ninput_size symbols,
+ * outs[i]: nblocks x output_vector_size samples for cyclic_shifts[i]. */
+int gfdm_hip_transmitter_work_host(gfdm_hip_transmitter* t, float* const* outs, int n_outs, const float* in, int ninput_size, int64_t nblocks);
+int gfdm_hip_transmitter_work_device(gfdm_hip_transmitter* t, void* const* outs, int n_outs, const void* in, int ninput_size,
+                                     int64_t nblocks, void* stream);
+/* modulate (lib/transmitter_kernel.cc:78-84): mapper + modulator, out = bare blocks */
+int gfdm_hip_transmitter_modulate_host(gfdm_hip_transmitter* t, float* out, const float* in, int ninput_size, int64_t nblocks);
+int gfdm_hip_transmitter_modulate_device(gfdm_hip_transmitter* t, void* out, const void* in, int ninput_size, int64_t nblocks, void* stream);
+/* add_frame (lib/transmitter_kernel.cc:92-98): preamble of `cyclic_shift` + cyclic prefix/suffix + ramp of modulated blocks */
+int gfdm_hip_transmitter_add_frame_host(gfdm_hip_transmitter* t, float* out, const float* in, int cyclic_shift, int64_t nblocks);
+int gfdm_hip_transmitter_add_frame_device(gfdm_hip_transmitter* t, void* out, const void* in, int cyclic_shift, int64_t nblocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
