@@ -10,6 +10,7 @@
 #include <gfdm/advanced_receiver_kernel_cc.h>
 #include <gfdm/modulator_kernel_cc.h>
 #include <gfdm/receiver_kernel_cc.h>
+#include <gfdm/transmitter_kernel.h>
 
 namespace py = pybind11;
 using namespace gr::gfdm;
@@ -182,4 +183,37 @@ PYBIND11_MODULE(gfdm_python, m)
             self.generic_work_batch(ptr(out), cptr(in), cptr(e), in.size / self.block_size());
             return result;
         });
+
+    // composite transmitter kernel (the reference only binds the GNU Radio block transmitter_cc,
+    // python/bindings/transmitter_cc_python.cc:36-70: same constructor argument order minus the length tag key)
+    py::class_<transmitter_kernel>(m, "Transmitter")
+        .def(py::init<int, int, int, int, int, int, std::vector<int>, bool, int, std::vector<cfloat>, std::vector<cfloat>, std::vector<int>,
+                      std::vector<std::vector<cfloat>>>(),
+             py::arg("timeslots"), py::arg("subcarriers"), py::arg("active_subcarriers"), py::arg("cp_len"), py::arg("cs_len"),
+             py::arg("ramp_len"), py::arg("subcarrier_map"), py::arg("per_timeslot"), py::arg("overlap"), py::arg("frequency_taps"),
+             py::arg("window_taps"), py::arg("cyclic_shifts"), py::arg("preambles"))
+        .def("input_vector_size", &transmitter_kernel::input_vector_size)
+        .def("output_vector_size", &transmitter_kernel::output_vector_size)
+        .def("cyclic_shifts", &transmitter_kernel::cyclic_shifts)
+        .def("kernel_name", &transmitter_kernel::kernel_name)
+        .def("transmit",
+             [](transmitter_kernel& self, const carray array, int n_ports) {
+                 py::buffer_info in = array.request();
+                 const int nin = self.input_vector_size();
+                 if (in.size == 0 || in.size % nin)
+                     throw std::runtime_error("Input size(" + std::to_string(in.size) + ") MUST be a multiple of input_vector_size(" +
+                                              std::to_string(nin) + ")!");
+                 const long nframes = in.size / nin;
+                 if (n_ports <= 0) n_ports = static_cast<int>(self.cyclic_shifts().size());
+                 std::vector<py::array_t<cfloat>> outs;
+                 std::vector<cfloat*> ptrs;
+                 for (int i = 0; i < n_ports; ++i) {
+                     outs.emplace_back(std::vector<py::ssize_t>{ nframes, self.output_vector_size() });
+                     ptrs.push_back(static_cast<cfloat*>(outs.back().request().ptr));
+                 }
+                 self.generic_work_batch(ptrs.data(), n_ports, cptr(in), nin, nframes);
+                 return outs;
+             },
+             py::arg("symbols"), py::arg("n_ports") = 0,
+             "frames of every cyclic shift (list of arrays [nframes, output_vector_size]) for nframes * input_vector_size symbols");
 }

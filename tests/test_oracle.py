@@ -144,3 +144,23 @@ def test_tap_normalisation_and_validation():
     assert rel_err(o3.filter_taps(), taps) < 1e-6
     with pytest.raises(ValueError):
         c_oracle.COracle(M, K, L, taps[:-1])
+
+
+# ---------------------------------------------------------------- composite transmitter oracles vs pygfdm frames
+
+def test_transmitter_oracles_match_pygfdm():
+    """python/qa_transmitter_cc.py:42-55 composition (map -> modulate -> roll -> cyclic starfix -> pinch -> preamble)."""
+    from conftest import load_tx_golden, tx_golden_names
+    for name in tx_golden_names():
+        g = load_tx_golden(name)
+        nt = R.normalize_taps(g["taps"], g["M"])
+        co = c_oracle.COracleTx(g["M"], g["K"], g["A"], g["cp"], g["cs"], g["ramp"], g["smap"], g["per_timeslot"], g["L"], g["taps"],
+                                g["window"], g["shifts"], g["preambles"])
+        assert co.n_in == g["A"] * g["M"] and co.n_out == g["pygfdm_frames"].shape[-1]
+        for port, s in enumerate(g["shifts"]):
+            ref = g["pygfdm_frames"][port]
+            got = R.transmit(g["symbols"], nt, g["M"], g["K"], g["L"], g["smap"], g["per_timeslot"], g["cp"], g["cs"], g["ramp"],
+                             g["window"], int(s), g["preambles"][port])
+            assert rel_err(got, ref) < 1e-7          # pygfdm's mapper rounds the symbols to complex64 (mapping.py:70)
+            assert rel_err(co.work(g["symbols"], port), ref) < TOL_F32
+            assert_places(co.work(g["symbols"], port), ref, 5)

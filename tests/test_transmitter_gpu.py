@@ -110,3 +110,21 @@ def test_transmitter_generic_family_and_validation():
         tx.transmit(np.zeros(A * M + 1, np.complex64), ninput_size=A * M + 1)
     with pytest.raises(ValueError, match="no preamble"):
         tx.add_frame(np.zeros(M * K, np.complex64), 1)
+
+
+def test_transmitter_pybind_surface():
+    """gfdm_python.Transmitter = gr::gfdm::transmitter_kernel (C++ class over the C-ABI): frames of every cyclic shift."""
+    import gfdm_python
+    g = load_tx_golden("tx_ref_k64_m9_cdd")
+    tx = gfdm_python.Transmitter(g["M"], g["K"], g["A"], g["cp"], g["cs"], g["ramp"], g["smap"].tolist(), g["per_timeslot"], g["L"],
+                                 g["taps"], g["window"], g["shifts"].tolist(), [p for p in g["preambles"]])
+    assert tx.input_vector_size() == g["A"] * g["M"] and tx.output_vector_size() == g["pygfdm_frames"].shape[-1]
+    assert list(tx.cyclic_shifts()) == [int(s) for s in g["shifts"]]
+    frames = tx.transmit(g["symbols"])
+    assert len(frames) == len(g["shifts"])
+    for port, fr in enumerate(frames):
+        assert fr.dtype == np.complex64 and fr.shape == g["pygfdm_frames"][port].shape
+        assert_places(fr, g["pygfdm_frames"][port], 5)
+    with pytest.raises(ValueError, match="do not match"):
+        gfdm_python.Transmitter(g["M"], g["K"], g["A"], g["cp"], g["cs"], g["ramp"], g["smap"].tolist(), True, g["L"], g["taps"], g["window"],
+                                [0, 1], [g["preambles"][0]])
