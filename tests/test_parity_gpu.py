@@ -374,3 +374,37 @@ def test_all_zero_and_tie_inputs_follow_the_reference_decision_rule():
     got = adv.demodulate(x)
     assert np.abs(ref).max() > 0.01            # the all-negative decisions leave a non-zero cancellation term
     assert rel_err(got, ref) < TOL
+
+
+def test_device_entry_points_are_graph_capturable():
+    """include/gfdm_hip.h promises that *_device calls only enqueue work (no allocation, no synchronisation): capture a
+    modulate -> demodulate -> IC chain into a HIP graph, replay it on new input, compare with the eager result."""
+    import torch
+    import gfdm_amd
+    from gfdm_amd import synth
+    dev = torch.device("cuda:0")
+    M, K, L, B = 9, 64, 2, 300
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+    sym = synth.qpsk_symbols(0, B, M * K, dev)
+    x, y, z = (torch.empty_like(sym) for _ in range(3))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                       # warm-up outside capture
+        mod.modulate(sym, out=x); dem.demodulate(x, out=y); adv.demodulate(x, out=z)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        mod.modulate(sym, out=x)
+        dem.demodulate(x, out=y)
+        adv.demodulate(x, out=z)
+    sym.copy_(synth.qpsk_symbols(777, B, M * K, dev))   # new input, same buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    nt = R.normalize_taps(taps, M)
+    s_h = sym.cpu().numpy()
+    ref_x = R.modulate(s_h, nt, M, K, L)
+    assert rel_err(x.cpu().numpy(), ref_x) < TOL
+    assert rel_err(y.cpu().numpy(), R.demodulate(ref_x, nt, M, K, L)) < TOL
+    assert float((z - sym).abs().max()) < 0.2
