@@ -135,6 +135,18 @@ __device__ void cancel_rows(cf* dst, const cf* td, const cf* fd, const DevicePla
     }
 }
 
+// resource demapper in the store stage: active subcarriers only, mapper order (resource_mapper_kernel_cc.cc:91-106,136-163)
+__device__ void emit_demapped(cf* o, const cf* tile, const RxIo& io, int K, int M)
+{
+    for (int idx = threadIdx.x; idx < K * M; idx += GT) {
+        const int k = idx / M, m = idx - k * M;
+        const int a = io.rank[k];
+        if (a < 0) continue;
+        const int dst = io.per_timeslot ? (m * io.A + a) : (a * M + m);
+        if (dst < io.nout) o[dst] = tile[idx];
+    }
+}
+
 __global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan p, TxParams tx, cf* __restrict__ out, const cf* __restrict__ in)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -208,8 +220,9 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams i
     cf* t1 = t0 + p.N;
     cf* t2 = t1 + p.N;                                             // only valid when 3 tiles were requested
     const int M = p.M, K = p.K, L = p.L, N = p.N;
-    const cf* x = in + (int64_t)blockIdx.x * N;
-    cf* o = out + (int64_t)blockIdx.x * N;
+    const cf* x = in + (int64_t)blockIdx.x * (int64_t)(ic.io.in_stride ? ic.io.in_stride : N) + ic.io.in_offset;   // frame -> block
+    const bool demap = ic.io.demap && mode != RX_FD;
+    cf* o = out + (int64_t)blockIdx.x * (demap ? ic.io.nout : N);
     const cf* eq = f_eq ? f_eq + (int64_t)blockIdx.x * N : nullptr;
 
     for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
@@ -246,7 +259,13 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams i
     __syncthreads();
     const float invM = 1.f / (float)M;
     if (mode == RX_DEMOD || ic.ic_iter <= 0) {
-        row_dft<true>(o, U, K, M, M, 1, p.wM, invM);              // d = IFFT_M(S_k) / M                :211-225
+        if (!demap) {
+            row_dft<true>(o, U, K, M, M, 1, p.wM, invM);          // d = IFFT_M(S_k) / M                :211-225
+        } else {
+            row_dft<true>(X, U, K, M, M, 1, p.wM, invM);
+            __syncthreads();
+            emit_demapped(o, X, ic.io, K, M);
+        }
         return;
     }
     cf* D = X;
@@ -287,7 +306,13 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams i
         cancel_rows(V, D, S, p);
         __syncthreads();
         if (j == ic.ic_iter - 1) {
-            row_dft<true>(o, V, K, M, M, 1, p.wM, invM);
+            if (!demap) {
+                row_dft<true>(o, V, K, M, M, 1, p.wM, invM);
+            } else {
+                row_dft<true>(D, V, K, M, M, 1, p.wM, invM);
+                __syncthreads();
+                emit_demapped(o, D, ic.io, K, M);
+            }
         } else {
             row_dft<true>(D, V, K, M, M, 1, p.wM, invM);
             __syncthreads();
@@ -356,6 +381,7 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, int m
     if (mode == RX_IC && ic.ic_iter > 0) {
         if (generic_lds_bytes(p.N, 3) <= LDS_MAX) ntiles = 3; else s_in_global = 1;
     }
+    if (s_in_global && ic.io.demap) return hipErrorInvalidConfiguration;   // the demapped output block is too small to park S in
     const size_t lds = generic_lds_bytes(p.N, ntiles);
     hipError_t e = allow_lds(k_generic_receive, lds);
     if (e != hipSuccess) return e;

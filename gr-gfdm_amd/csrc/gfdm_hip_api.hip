@@ -205,26 +205,34 @@ int ensure_stage(Plan& pl, int slot, size_t elems)
 }
 
 // Host-pointer convenience path: H2D, launch, D2H, wait.  `launch(out, in0, in1, stream)` enqueues the kernels.
+// Host-pointer convenience path: H2D, launch, D2H, wait.  `launch(out, in0, in1, stream)` enqueues the kernels.
+// Element counts are per call (frames in / demapped symbols out may differ from nblocks * N).
+template <typename Launch>
+int run_host_sized(Plan& pl, float* out, size_t out_elems, const float* in0, size_t in0_elems, const float* in1, size_t in1_elems, Launch launch)
+{
+    if (out == nullptr || in0 == nullptr) return fail(GFDM_HIP_EINVAL, "NULL buffer");
+    if (out_elems == 0 || in0_elems == 0) return GFDM_HIP_OK;
+    DeviceGuard guard(pl.device);
+    if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
+    int rc;
+    if ((rc = ensure_stage(pl, 0, out_elems)) != GFDM_HIP_OK) return rc;
+    if ((rc = ensure_stage(pl, 1, in0_elems)) != GFDM_HIP_OK) return rc;
+    if (in1 && (rc = ensure_stage(pl, 2, in1_elems)) != GFDM_HIP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(pl.stage[1], in0, in0_elems * sizeof(cf), hipMemcpyHostToDevice, pl.stream));
+    if (in1) HIP_TRY(hipMemcpyAsync(pl.stage[2], in1, in1_elems * sizeof(cf), hipMemcpyHostToDevice, pl.stream));
+    hipError_t e = launch(pl.stage[0], pl.stage[1], in1 ? pl.stage[2] : nullptr, pl.stream);
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    HIP_TRY(hipMemcpyAsync(out, pl.stage[0], out_elems * sizeof(cf), hipMemcpyDeviceToHost, pl.stream));
+    HIP_TRY(hipStreamSynchronize(pl.stream));
+    return GFDM_HIP_OK;
+}
+
 template <typename Launch>
 int run_host(Plan& pl, float* out, const float* in0, const float* in1, int64_t nblocks, Launch launch)
 {
     if (nblocks < 0 || out == nullptr || in0 == nullptr) return fail(GFDM_HIP_EINVAL, "NULL buffer or negative block count");
-    if (nblocks == 0) return GFDM_HIP_OK;
-    DeviceGuard guard(pl.device);
-    if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
     const size_t elems = (size_t)nblocks * (size_t)pl.dp.N;
-    const size_t bytes = elems * sizeof(cf);
-    int rc;
-    if ((rc = ensure_stage(pl, 0, elems)) != GFDM_HIP_OK) return rc;
-    if ((rc = ensure_stage(pl, 1, elems)) != GFDM_HIP_OK) return rc;
-    if (in1 && (rc = ensure_stage(pl, 2, elems)) != GFDM_HIP_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(pl.stage[1], in0, bytes, hipMemcpyHostToDevice, pl.stream));
-    if (in1) HIP_TRY(hipMemcpyAsync(pl.stage[2], in1, bytes, hipMemcpyHostToDevice, pl.stream));
-    hipError_t e = launch(pl.stage[0], pl.stage[1], in1 ? pl.stage[2] : nullptr, pl.stream);
-    if (e != hipSuccess) return fail_hip(e, "kernel launch");
-    HIP_TRY(hipMemcpyAsync(out, pl.stage[0], bytes, hipMemcpyDeviceToHost, pl.stream));
-    HIP_TRY(hipStreamSynchronize(pl.stream));
-    return GFDM_HIP_OK;
+    return run_host_sized(pl, out, elems, in0, elems, in1, elems, launch);
 }
 
 template <typename Launch>
@@ -243,7 +251,8 @@ hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, cons
                             hipStream_t s)
 {
     if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
-    if (pl.family == gfdm::FAMILY_FAST) return gfdm::launch_fast_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    const bool plain_io = !ic.io.demap && !ic.io.in_offset && (ic.io.in_stride == 0 || ic.io.in_stride == pl.dp.N);
+    if (pl.family == gfdm::FAMILY_FAST && plain_io) return gfdm::launch_fast_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
     return gfdm::launch_generic_receive(pl.dp, ic, mode, out, in, f_eq, nblocks, s);
 }
 
@@ -261,9 +270,64 @@ const gfdm::IcParams kNoIc = { 0, 0, 0, 0, nullptr, nullptr, 0, nullptr };
 }  // namespace
 
 struct gfdm_hip_modulator { Plan plan; };
-struct gfdm_hip_receiver { Plan plan; };
+// frame input (cyclic prefix removal) + demapped output, shared by receiver and advanced receiver handles
+struct FrameIo {
+    gfdm::RxIo io{};
+    void* d_rank = nullptr;
+    int device = 0;
+    bool configured = false;
+    ~FrameIo()
+    {
+        if (d_rank) {
+            DeviceGuard guard(device);
+            (void)hipFree(d_rank);
+        }
+    }
+};
+
+int frame_io_configure(FrameIo& f, const Plan& pl, int frame_len, int cp_len, const int* smap, int n_map, int per_timeslot)
+{
+    const int N = pl.dp.N, K = pl.dp.K, M = pl.dp.M;
+    if (cp_len < 0 || frame_len < cp_len + N) return fail(GFDM_HIP_EINVAL, "frame_len must be at least cp_len + block size");
+    if (n_map < 0 || n_map > K || (n_map > 0 && !smap)) return fail(GFDM_HIP_EINVAL, "bad subcarrier_map");
+    std::vector<int> sorted(smap, smap + n_map);
+    std::sort(sorted.begin(), sorted.end());                      // the reference constructor sorts the map (resource_mapper_kernel_cc.cc:55)
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(GFDM_HIP_EINVAL, "All entries in subcarrier_map MUST be unique!");
+    if (n_map > 0 && (sorted.front() < 0 || sorted.back() >= K)) return fail(GFDM_HIP_EINVAL, "subcarrier_map entry out of range");
+    std::vector<short> rank(K, (short)-1);
+    for (int a = 0; a < n_map; ++a) rank[sorted[a]] = (short)a;
+    DeviceGuard guard(pl.device);
+    if (!f.d_rank) HIP_TRY(hipMalloc(&f.d_rank, (size_t)K * sizeof(short)));
+    HIP_TRY(hipMemcpy(f.d_rank, rank.data(), (size_t)K * sizeof(short), hipMemcpyHostToDevice));
+    f.device = pl.device;
+    f.io.in_stride = frame_len; f.io.in_offset = cp_len;
+    f.io.demap = n_map > 0 ? 1 : 0; f.io.per_timeslot = per_timeslot ? 1 : 0; f.io.A = n_map;
+    f.io.nout = n_map > 0 ? n_map * M : N;
+    f.io.rank = reinterpret_cast<const short*>(f.d_rank);
+    f.configured = true;
+    return GFDM_HIP_OK;
+}
+
+// effective I/O of one frames call; noutput_size <= 0 selects everything
+int frame_io_for_call(const FrameIo& f, const Plan& pl, int noutput_size, gfdm::RxIo& io)
+{
+    if (!f.configured) return fail(GFDM_HIP_EINVAL, "configure_frames has not been called on this handle");
+    io = f.io;
+    if (io.demap) {
+        if (noutput_size > io.A * pl.dp.M) {
+            char buf[200];
+            snprintf(buf, sizeof(buf), "output vector size(%d) MUST not exceed active_subcarriers * timeslots(%d)!", noutput_size, io.A * pl.dp.M);
+            return fail(GFDM_HIP_EINVAL, buf);                     // resource_mapper_kernel_cc.cc:95-99
+        }
+        if (noutput_size > 0) io.nout = noutput_size;
+    }
+    return GFDM_HIP_OK;
+}
+
+struct gfdm_hip_receiver { Plan plan; FrameIo frames; };
 struct gfdm_hip_advanced_receiver {
     Plan plan;
+    FrameIo frames;
     gfdm::IcParams ic{};
     void* d_ic = nullptr;     // points | smap | active
     ~gfdm_hip_advanced_receiver()
@@ -552,6 +616,78 @@ int gfdm_hip_advanced_receiver_work_host(gfdm_hip_advanced_receiver* a, float* o
     if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
     return run_host(a->plan, out, in, f_eq, nblocks, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
         return rx_launch(a->plan, a->ic, gfdm::RX_IC, o, i, e, nblocks, s);
+    });
+}
+
+}  // extern "C"
+
+// ---- receiver / advanced receiver on raw frames with demapped output ----
+
+extern "C" {
+
+int gfdm_hip_receiver_configure_frames(gfdm_hip_receiver* r, int frame_len, int cp_len, const int* subcarrier_map, int n_subcarrier_map,
+                                       int per_timeslot)
+{
+    if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    return frame_io_configure(r->frames, r->plan, frame_len, cp_len, subcarrier_map, n_subcarrier_map, per_timeslot);
+}
+
+int gfdm_hip_advanced_receiver_configure_frames(gfdm_hip_advanced_receiver* a, int frame_len, int cp_len, const int* subcarrier_map,
+                                                int n_subcarrier_map, int per_timeslot)
+{
+    if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    return frame_io_configure(a->frames, a->plan, frame_len, cp_len, subcarrier_map, n_subcarrier_map, per_timeslot);
+}
+
+int gfdm_hip_receiver_demodulate_frames_device(gfdm_hip_receiver* r, void* out, const void* in, const void* f_eq, int noutput_size,
+                                               int64_t nblocks, void* stream)
+{
+    if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    gfdm::IcParams ic = kNoIc;
+    int rc = frame_io_for_call(r->frames, r->plan, noutput_size, ic.io);
+    if (rc != GFDM_HIP_OK) return rc;
+    return run_device(r->plan, out, in, nblocks, [&]() {
+        return rx_launch(r->plan, ic, gfdm::RX_DEMOD, (cf*)out, (const cf*)in, (const cf*)f_eq, nblocks, (hipStream_t)stream);
+    });
+}
+
+int gfdm_hip_advanced_receiver_work_frames_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* f_eq,
+                                                  int noutput_size, int64_t nblocks, void* stream)
+{
+    if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    gfdm::IcParams ic = a->ic;
+    int rc = frame_io_for_call(a->frames, a->plan, noutput_size, ic.io);
+    if (rc != GFDM_HIP_OK) return rc;
+    return run_device(a->plan, out, in, nblocks, [&]() {
+        return rx_launch(a->plan, ic, gfdm::RX_IC, (cf*)out, (const cf*)in, (const cf*)f_eq, nblocks, (hipStream_t)stream);
+    });
+}
+
+int gfdm_hip_receiver_demodulate_frames_host(gfdm_hip_receiver* r, float* out, const float* in, const float* f_eq, int noutput_size,
+                                             int64_t nblocks)
+{
+    if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    if (nblocks < 0) return fail(GFDM_HIP_EINVAL, "negative block count");
+    gfdm::RxIo io;
+    int rc = frame_io_for_call(r->frames, r->plan, noutput_size, io);
+    if (rc != GFDM_HIP_OK) return rc;
+    const size_t nb = (size_t)nblocks;
+    return run_host_sized(r->plan, out, nb * io.nout, in, nb * io.in_stride, f_eq, nb * r->plan.dp.N, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
+        return (hipError_t)(gfdm_hip_receiver_demodulate_frames_device(r, o, i, e, noutput_size, nblocks, (void*)s) == GFDM_HIP_OK ? hipSuccess : hipErrorUnknown);
+    });
+}
+
+int gfdm_hip_advanced_receiver_work_frames_host(gfdm_hip_advanced_receiver* a, float* out, const float* in, const float* f_eq,
+                                                int noutput_size, int64_t nblocks)
+{
+    if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    if (nblocks < 0) return fail(GFDM_HIP_EINVAL, "negative block count");
+    gfdm::RxIo io;
+    int rc = frame_io_for_call(a->frames, a->plan, noutput_size, io);
+    if (rc != GFDM_HIP_OK) return rc;
+    const size_t nb = (size_t)nblocks;
+    return run_host_sized(a->plan, out, nb * io.nout, in, nb * io.in_stride, f_eq, nb * a->plan.dp.N, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
+        return (hipError_t)(gfdm_hip_advanced_receiver_work_frames_device(a, o, i, e, noutput_size, nblocks, (void*)s) == GFDM_HIP_OK ? hipSuccess : hipErrorUnknown);
     });
 }
 

@@ -26,7 +26,21 @@ struct DevicePlan {
     const cf* wN;       // [N]   exp(-2 pi j r / N)
 };
 
-// Interference-cancellation settings of advanced_receiver_kernel_cc.
+// Where the receiver finds its samples and how it emits its symbols: the cyclic-prefix removal
+// of add_cyclic_prefix_cc::remove_cyclic_prefix (lib/add_cyclic_prefix_cc.cc:100-104) is an input offset + stride, the
+// resource demapper resource_mapper_kernel_cc::demap_from_resources (lib/resource_mapper_kernel_cc.cc:91-106,136-163)
+// a gather in the store stage.  All zero = plain blocks in, plain [k][m] blocks out.
+struct RxIo {
+    int in_stride;             // samples between consecutive frames in the input (0 = block size N)
+    int in_offset;             // samples to skip at the start of every frame (cyclic prefix length)
+    int demap;                 // 1: emit only the active subcarriers, in mapper order
+    int per_timeslot;          // demapper symbol order
+    int A;                     // active subcarriers
+    int nout;                  // symbols emitted per block (<= A * M) = output stride
+    const short* rank;         // [K] position of subcarrier k in the sorted subcarrier map, -1 when inactive
+};
+
+// Interference-cancellation settings of advanced_receiver_kernel_cc (+ the I/O layout above).
 struct IcParams {
     int ic_iter;
     int do_phase_compensation;
@@ -36,6 +50,7 @@ struct IcParams {
     const unsigned char* active;   // [K] how often the subcarrier occurs in subcarrier_map (0 = inactive)
     int n_active;              // subcarrier_map.size() (duplicates counted, as the reference does)
     const int* smap;           // [n_active] the subcarrier_map itself (order matters for the phase sum)
+    RxIo io;
 };
 
 enum RxMode {

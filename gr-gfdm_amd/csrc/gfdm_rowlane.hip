@@ -215,12 +215,13 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     const int64_t blk = (int64_t)blockIdx.x * S::BPW + g;
     const bool valid = blk < nblocks;
     const int64_t base = (valid ? blk : 0) * N;
+    const int64_t in_base = (valid ? blk : 0) * (int64_t)(ic.io.in_stride ? ic.io.in_stride : N) + ic.io.in_offset;   // frame -> block
     cf* X = reinterpret_cast<cf*>(smem) + g * T::TS;                   // the block's single LDS tile, [row][M]
 
     GFDM_STAMP(0);
     // ---- phase A: timeslot DFT of row q, twiddle W_N^{q m}
     cf v[M];
-    static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = in[base + K * pp + q]; });
+    static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = in[in_base + K * pp + q]; });
     cf tw[M];
     static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; tw[m] = twT[m * K + q]; });
     GFDM_STAMP(1);
@@ -369,11 +370,25 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     }
 
     GFDM_STAMP(4);
-    // ---- output: row -> tile, linear read, coalesced store
-    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = (MODE == RX_FD) ? s[m] : d[m]; });
-    block_sync<K>();
-    if (valid) {
-        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; out[base + q + K * i] = X[q + K * i]; });
+    if (MODE != RX_FD && ic.io.demap) {
+        // resource demapper fused into the store: only active subcarriers, in mapper order; for per-timeslot order the lanes of
+        // one timeslot write consecutive output symbols, so no LDS staging is needed                     mapper:91-106,136-163
+        const int a = ic.io.rank[q];
+        if (valid && a >= 0) {
+            cf* o = out + blk * (int64_t)ic.io.nout;
+            static_for<0, M>([&](auto mi) {
+                constexpr int m = decltype(mi)::value;
+                const int idx = ic.io.per_timeslot ? (m * ic.io.A + a) : (a * M + m);
+                if (idx < ic.io.nout) o[idx] = d[m];
+            });
+        }
+    } else {
+        // ---- output: row -> tile, linear read, coalesced store
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = (MODE == RX_FD) ? s[m] : d[m]; });
+        block_sync<K>();
+        if (valid) {
+            static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; out[base + q + K * i] = X[q + K * i]; });
+        }
     }
     GFDM_STAMP(5);
 }

@@ -75,6 +75,12 @@ def lib():
         "gfdm_hip_advanced_receiver_kernel_name": (cp, [vp]),
         "gfdm_hip_advanced_receiver_work_host": (i32, [vp, vp, vp, vp, i64]),
         "gfdm_hip_advanced_receiver_work_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_configure_frames": (i32, [vp, i32, i32, vp, i32, i32]),
+        "gfdm_hip_receiver_demodulate_frames_host": (i32, [vp, vp, vp, vp, i32, i64]),
+        "gfdm_hip_receiver_demodulate_frames_device": (i32, [vp, vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_advanced_receiver_configure_frames": (i32, [vp, i32, i32, vp, i32, i32]),
+        "gfdm_hip_advanced_receiver_work_frames_host": (i32, [vp, vp, vp, vp, i32, i64]),
+        "gfdm_hip_advanced_receiver_work_frames_device": (i32, [vp, vp, vp, vp, i32, i64, vp]),
         "gfdm_hip_transmitter_create": (i32, [ctypes.POINTER(vp)] + [i32] * 6 + [vp, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32]),
         "gfdm_hip_transmitter_destroy": (i32, [vp]),
         "gfdm_hip_transmitter_input_vector_size": (i32, [vp]),
@@ -142,6 +148,43 @@ def _stream_ptr(stream):
 class _Kernel:
     """Shared plumbing: host (numpy) and device (torch) batched calls."""
     _destroy = None
+    _frames_prefix = None          # C-ABI name stem of the *_frames_* entry points (receivers only)
+    _configure_frames = None
+
+    # ---- raw frames in, demapped symbols out (SURVEY.md section 8f row 2) ----
+    def configure_frames(self, frame_len, cp_len, subcarrier_map=None, per_timeslot=True):
+        """Declare the frame layout once: frames of frame_len samples whose block starts cp_len samples in; with a
+        subcarrier_map only the active subcarriers' symbols are emitted, in resource-mapper order."""
+        smap = np.ascontiguousarray([] if subcarrier_map is None else subcarrier_map, dtype=np.int32)
+        fn = getattr(lib(), self._configure_frames)
+        _check(fn(self._h, int(frame_len), int(cp_len), smap.ctypes.data if smap.size else None, smap.size, int(bool(per_timeslot))))
+        self._frame_len = int(frame_len)
+        self._frame_nout = smap.size * (self.block_size() // self._frame_k) if smap.size else self.block_size()
+
+    def demodulate_frames(self, frames, f_eq=None, noutput_size=None, out=None, stream=None):
+        """frames: nframes * frame_len samples; returns (nframes, noutput_size) symbols (all active symbols by default)."""
+        L = lib()
+        nout_arg = -1 if noutput_size is None else int(noutput_size)
+        nout = self._frame_nout if noutput_size is None else int(noutput_size)
+        N = self.block_size()
+        if _is_tensor(frames):
+            import torch
+            nb = frames.numel() // self._frame_len
+            out = torch.empty(nb, nout, dtype=torch.complex64, device=frames.device) if out is None else out
+            feq = None if f_eq is None else _dev_ptr(f_eq, nb * N, "f_eq")
+            _check(getattr(L, self._frames_prefix + "_device")(self._h, _dev_ptr(out, nb * nout, "out"), _dev_ptr(frames, nb * self._frame_len, "frames"),
+                                                              feq, nout_arg, nb, _stream_ptr(stream)))
+            return out
+        x = _c64(frames)
+        if x.size % self._frame_len:
+            raise RuntimeError("frames size(%d) MUST be a multiple of frame_len(%d)!" % (x.size, self._frame_len))
+        nb = x.size // self._frame_len
+        e = None if f_eq is None else _c64(f_eq)
+        if e is not None and e.size != nb * N:
+            raise RuntimeError("Channel vector size(%d) MUST be equal to nframes * block_size(%d)!" % (e.size, nb * N))
+        res = np.empty((nb, nout), np.complex64)
+        _check(getattr(L, self._frames_prefix + "_host")(self._h, res.ctypes.data, x.ctypes.data, None if e is None else e.ctypes.data, nout_arg, nb))
+        return res
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -224,6 +267,8 @@ class Modulator(_Kernel):
 class Demodulator(_Kernel):
     """gr::gfdm::receiver_kernel_cc (include/gfdm/receiver_kernel_cc.h:52-89) on the GPU."""
     _destroy = "gfdm_hip_receiver_destroy"
+    _frames_prefix = "gfdm_hip_receiver_demodulate_frames"
+    _configure_frames = "gfdm_hip_receiver_configure_frames"
 
     def __init__(self, timeslots, subcarriers, overlap, taps, device=0):
         L = lib()
@@ -232,6 +277,7 @@ class Demodulator(_Kernel):
         _check(L.gfdm_hip_receiver_create(ctypes.byref(h), timeslots, subcarriers, overlap, tp, tn, device))
         self._h = h
         self._M, self._K, self._L = timeslots, subcarriers, overlap
+        self._frame_k = subcarriers
 
     def timeslots(self):
         return lib().gfdm_hip_receiver_timeslots(self._h)
@@ -291,6 +337,8 @@ class AdvancedReceiver(_Kernel):
     The reference takes a gr::digital::constellation_sptr; here the constellation is its points() array plus a
     decision rule ('auto' picks the QPSK/BPSK sign tests when the points are those constellations)."""
     _destroy = "gfdm_hip_advanced_receiver_destroy"
+    _frames_prefix = "gfdm_hip_advanced_receiver_work_frames"
+    _configure_frames = "gfdm_hip_advanced_receiver_configure_frames"
 
     def __init__(self, timeslots, subcarriers, overlap, taps, subcarrier_map, ic_iter, constellation_points,
                  do_phase_compensation=0, decision="auto", device=0):
@@ -304,6 +352,7 @@ class AdvancedReceiver(_Kernel):
                                                    DECIDE[decision], do_phase_compensation, device))
         self._h = h
         self._n = timeslots * subcarriers
+        self._frame_k = subcarriers
 
     def block_size(self):
         return self._n

@@ -125,6 +125,27 @@ const char* gfdm_hip_advanced_receiver_kernel_name(const gfdm_hip_advanced_recei
 int gfdm_hip_advanced_receiver_work_host(gfdm_hip_advanced_receiver* a, float* out, const float* in, const float* f_eq, int64_t nblocks);
 int gfdm_hip_advanced_receiver_work_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* f_eq, int64_t nblocks, void* stream);
 
+/* ---- receivers on raw frames with demapped output -----------------------------------
+ * In the reference flowgraph the receiver sits between remove_prefix (add_cyclic_prefix_cc::remove_cyclic_prefix,
+ * lib/add_cyclic_prefix_cc.cc:100-104) and the resource demapper (resource_mapper_kernel_cc::demap_from_resources,
+ * lib/resource_mapper_kernel_cc.cc:91-106,136-163).  Here both are the receiver kernel's load / store stage:
+ * configure_frames declares the frame layout once, the *_frames_* calls then read frames of frame_len samples (the block
+ * starts cp_len samples in) and write only the active subcarriers' symbols in mapper order, noutput_size per frame
+ * (<= 0: all of them).  n_subcarrier_map == 0 keeps the plain [k][m] block output.  f_eq stays one block_size vector per frame.
+ * The demapper walks the SORTED map, as the reference constructor does. */
+int gfdm_hip_receiver_configure_frames(gfdm_hip_receiver* r, int frame_len, int cp_len, const int* subcarrier_map, int n_subcarrier_map,
+                                       int per_timeslot);
+int gfdm_hip_receiver_demodulate_frames_host(gfdm_hip_receiver* r, float* out, const float* in, const float* f_eq, int noutput_size,
+                                             int64_t nblocks);
+int gfdm_hip_receiver_demodulate_frames_device(gfdm_hip_receiver* r, void* out, const void* in, const void* f_eq, int noutput_size,
+                                               int64_t nblocks, void* stream);
+int gfdm_hip_advanced_receiver_configure_frames(gfdm_hip_advanced_receiver* a, int frame_len, int cp_len, const int* subcarrier_map,
+                                                int n_subcarrier_map, int per_timeslot);
+int gfdm_hip_advanced_receiver_work_frames_host(gfdm_hip_advanced_receiver* a, float* out, const float* in, const float* f_eq,
+                                                int noutput_size, int64_t nblocks);
+int gfdm_hip_advanced_receiver_work_frames_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* f_eq,
+                                                  int noutput_size, int64_t nblocks, void* stream);
+
 /* ---- transmitter_kernel (include/gfdm/transmitter_kernel.h:43-85) -------------
  * resource mapper -> modulator -> cyclic prefix / suffix with cyclic shift + window ramp -> preamble, FUSED into one HIP kernel:
  * the mapper is the modulator's load stage, prefix/suffix/ramp/preamble its store stage, for all cyclic shifts ("ports") at once. */

@@ -233,3 +233,24 @@ def transmit(symbols, ntaps, M, K, L, smap, per_timeslot, cp_len, cs_len, ramp_l
     body = add_cyclic_prefix(block, cp_len, cs_len, ramp_len, window_taps, cyclic_shift)
     pre = np.broadcast_to(_c128(preamble), body.shape[:-1] + (len(preamble),))
     return np.concatenate((pre, body), axis=-1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Receiver-side counterparts: cyclic prefix removal in front, resource demapper behind
+
+def remove_cyclic_prefix(frames, cp_len, block_len):
+    """add_cyclic_prefix_cc::remove_cyclic_prefix -- lib/add_cyclic_prefix_cc.cc:100-104."""
+    return _c128(frames)[..., cp_len:cp_len + block_len]
+
+
+def demap_from_resources(grid, M, K, smap, per_timeslot=True, noutput_size=None):
+    """resource_mapper_kernel_cc::demap_from_resources -- lib/resource_mapper_kernel_cc.cc:91-106,136-163 (sorted map).
+    grid: (..., K*M) subcarrier-major; returns (..., noutput_size) symbols in mapper order.  (The reference's
+    per-subcarrier loop writes one element past noutput_size when truncating, :157-161; that overrun is not restated.)"""
+    g = _c128(grid)
+    batch = g.shape[:-1]
+    smap = np.sort(np.asarray(smap, dtype=np.int64))
+    act = g.reshape(batch + (K, M))[..., smap, :]                       # (..., A, M)
+    out = np.swapaxes(act, -1, -2) if per_timeslot else act             # per timeslot: symbol t*A + a
+    out = out.reshape(batch + (len(smap) * M,))
+    return out if noutput_size is None else out[..., :noutput_size]

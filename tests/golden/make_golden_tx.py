@@ -66,3 +66,30 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def add_rx_expectations():
+    """Receiver-side chain on the transmitter frames, with the reference model where it is
+    valid (overlap 2): frame (port 0, preamble stripped) -> remove cyclic prefix (slice, cyclic_prefix.py) ->
+    gfdm_demodulate_block -> demap_from_waveform_resource_grid (per-timeslot order, mapping.py:56-59).  Stored next to the
+    transmitter vectors as `pygfdm_rx_symbols`."""
+    from pygfdm.gfdm_receiver import gfdm_demodulate_block
+    from pygfdm.mapping import demap_from_waveform_resource_grid
+    for name, M, K, A, dc_free, L, alpha, cp, cs, ramp, per_ts, shifts, plen, frames, nsym in CASES:
+        path = os.path.join(HERE, name + ".npz")
+        z = dict(np.load(path))
+        if L != 2 or not per_ts:
+            continue
+        rx = []
+        for f in range(frames):
+            body = z["pygfdm_frames"][0][f][plen:]                      # window ramp only touches prefix / suffix samples here
+            block = body[cp:cp + M * K]
+            d = gfdm_demodulate_block(block, z["taps"], K, M, L)
+            rx.append(demap_from_waveform_resource_grid(d, K, z["smap"]))
+        z["pygfdm_rx_symbols"] = np.array(rx)
+        np.savez_compressed(path, **z)
+        print(name, "rx symbols", z["pygfdm_rx_symbols"].shape)
+
+
+if __name__ == "__main__":
+    add_rx_expectations()
