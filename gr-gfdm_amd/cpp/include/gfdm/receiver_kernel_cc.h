@@ -53,6 +53,13 @@ public:
     void fft_filter_downsample_device(void* d_out, const void* d_in, const void* d_f_eq, long nblocks, void* hip_stream);
     void transform_subcarriers_to_td_device(void* d_out, const void* d_in, long nblocks, void* hip_stream);
     void cancel_sc_interference_device(void* d_out, const void* d_td_in, const void* d_fd_in, long nblocks, void* hip_stream);
+    /* --- additions: raw frames in, demapped symbols out (what remove_prefix -> receiver -> resource_demapper compute in
+     * the reference flowgraph, as ONE kernel).  configure_frames declares the layout once: frames of frame_len samples whose
+     * block starts cp_len samples in; with a non-empty subcarrier_map only the active subcarriers' symbols are written, in
+     * resource-mapper order, noutput_size per frame (<= 0: all).  f_eq_in (may be nullptr) stays one block per frame. --- */
+    void configure_frames(int frame_len, int cp_len, std::vector<int> subcarrier_map, bool per_timeslot);
+    void generic_work_frames_batch(gfdm_complex* out, const gfdm_complex* in, const gfdm_complex* f_eq_in, int noutput_size, long nframes);
+    void generic_work_frames_device(void* d_out, const void* d_in, const void* d_f_eq, int noutput_size, long nframes, void* hip_stream);
     const char* kernel_name() const;
 
 private:

@@ -13,7 +13,7 @@ void raise(int status, const char* where)
     if (status == GFDM_HIP_OK) return;
     const char* detail = gfdm_hip_last_error();
     std::string msg = (detail && *detail) ? detail : gfdm_hip_strerror(status);
-    if (status == GFDM_HIP_EINVAL_TAPS || status == GFDM_HIP_EINVAL_OVERLAP) throw std::invalid_argument(msg);
+    if (status == GFDM_HIP_EINVAL_TAPS || status == GFDM_HIP_EINVAL_OVERLAP || status == GFDM_HIP_EINVAL) throw std::invalid_argument(msg);
     throw std::runtime_error(std::string(where) + ": " + msg);
 }
 inline float* fp(gr_complex_t* p) { return reinterpret_cast<float*>(p); }
@@ -87,6 +87,27 @@ void advanced_receiver_kernel_cc::set_phase_compensation(int do_phase_compensati
     raise(gfdm_hip_advanced_receiver_set_phase_compensation(d_handle, do_phase_compensation), "set_phase_compensation");
 }
 int advanced_receiver_kernel_cc::get_phase_compensation() { return gfdm_hip_advanced_receiver_get_phase_compensation(d_handle); }
+void advanced_receiver_kernel_cc::configure_frames(int frame_len, int cp_len, std::vector<int> subcarrier_map, bool per_timeslot)
+{
+    raise(gfdm_hip_advanced_receiver_configure_frames(d_handle, frame_len, cp_len, subcarrier_map.data(),
+                                                      static_cast<int>(subcarrier_map.size()), per_timeslot ? 1 : 0),
+          "configure_frames");
+}
+
+void advanced_receiver_kernel_cc::generic_work_frames_batch(gr_complex_t* out, const gr_complex_t* in, const gr_complex_t* f_eq_in,
+                                                            int noutput_size, long nframes)
+{
+    raise(gfdm_hip_advanced_receiver_work_frames_host(d_handle, fp(out), fp(in), fp(f_eq_in), noutput_size, nframes),
+          "advanced receiver generic_work_frames");
+}
+
+void advanced_receiver_kernel_cc::generic_work_frames_device(void* d_out, const void* d_in, const void* d_f_eq, int noutput_size,
+                                                             long nframes, void* hip_stream)
+{
+    raise(gfdm_hip_advanced_receiver_work_frames_device(d_handle, d_out, d_in, d_f_eq, noutput_size, nframes, hip_stream),
+          "advanced receiver generic_work_frames_device");
+}
+
 const char* advanced_receiver_kernel_cc::kernel_name() const { return gfdm_hip_advanced_receiver_kernel_name(d_handle); }
 
 } // namespace gfdm

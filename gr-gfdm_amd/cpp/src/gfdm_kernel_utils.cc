@@ -17,7 +17,7 @@ void gfdm_kernel_utils::throw_on_error(int status, const char* where)
     if (status == GFDM_HIP_OK) return;
     const char* detail = gfdm_hip_last_error();
     std::string msg = (detail && *detail) ? detail : gfdm_hip_strerror(status);
-    if (status == GFDM_HIP_EINVAL_TAPS || status == GFDM_HIP_EINVAL_OVERLAP)
+    if (status == GFDM_HIP_EINVAL_TAPS || status == GFDM_HIP_EINVAL_OVERLAP || status == GFDM_HIP_EINVAL)
         throw std::invalid_argument(msg);            // what the reference constructors throw
     throw std::runtime_error(std::string(where) + ": " + msg);
 }

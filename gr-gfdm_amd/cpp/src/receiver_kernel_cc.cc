@@ -95,6 +95,27 @@ void receiver_kernel_cc::cancel_sc_interference_device(void* d_out, const void* 
                    "cancel_sc_interference_device");
 }
 
+void receiver_kernel_cc::configure_frames(int frame_len, int cp_len, std::vector<int> subcarrier_map, bool per_timeslot)
+{
+    throw_on_error(gfdm_hip_receiver_configure_frames(d_handle, frame_len, cp_len, subcarrier_map.data(),
+                                                      static_cast<int>(subcarrier_map.size()), per_timeslot ? 1 : 0),
+                   "configure_frames");
+}
+
+void receiver_kernel_cc::generic_work_frames_batch(gfdm_complex* out, const gfdm_complex* in, const gfdm_complex* f_eq_in, int noutput_size,
+                                                   long nframes)
+{
+    throw_on_error(gfdm_hip_receiver_demodulate_frames_host(d_handle, fp(out), fp(in), fp(f_eq_in), noutput_size, nframes),
+                   "receiver generic_work_frames");
+}
+
+void receiver_kernel_cc::generic_work_frames_device(void* d_out, const void* d_in, const void* d_f_eq, int noutput_size, long nframes,
+                                                    void* hip_stream)
+{
+    throw_on_error(gfdm_hip_receiver_demodulate_frames_device(d_handle, d_out, d_in, d_f_eq, noutput_size, nframes, hip_stream),
+                   "receiver generic_work_frames_device");
+}
+
 const char* receiver_kernel_cc::kernel_name() const { return gfdm_hip_receiver_kernel_name(d_handle); }
 
 // ---- legacy 2-D API: [subcarrier][timeslot] vectors <-> the flat subcarrier-major block ----

@@ -12,6 +12,8 @@
 #include <gfdm/receiver_kernel_cc.h>
 #include <gfdm/transmitter_kernel.h>
 
+#include <unordered_map>
+
 namespace py = pybind11;
 using namespace gr::gfdm;
 
@@ -68,6 +70,33 @@ py::array_t<cfloat> rx_binary(receiver_kernel_cc& self, const carray& array, con
     fn(ptr(out), cptr(in), cptr(in2));
     return result;
 }
+
+// frames of frame_len samples in, (nframes, noutput) demapped symbols out
+template <typename Kernel>
+py::array_t<cfloat> run_frames(Kernel& self, const carray& frames, py::object eq, int frame_len, int nout_all, int noutput_size)
+{
+    py::buffer_info in = frames.request();
+    if (frame_len <= 0 || in.size % frame_len)
+        throw std::runtime_error("frames size(" + std::to_string(in.size) + ") MUST be a multiple of frame_len(" + std::to_string(frame_len) + ")!");
+    const long nframes = in.size / frame_len;
+    const int nout = noutput_size > 0 ? noutput_size : nout_all;
+    py::array_t<cfloat> result(std::vector<py::ssize_t>{ nframes, nout });
+    py::buffer_info out = result.request();
+    if (eq.is_none()) {
+        self.generic_work_frames_batch(ptr(out), cptr(in), nullptr, noutput_size, nframes);
+    } else {
+        carray eq_arr = eq.cast<carray>();
+        py::buffer_info e = eq_arr.request();
+        if (e.size != nframes * self.block_size())
+            throw std::runtime_error("Channel vector size(" + std::to_string(e.size) + ") MUST be equal to nframes * block_size!");
+        self.generic_work_frames_batch(ptr(out), cptr(in), cptr(e), noutput_size, nframes);
+    }
+    return result;
+}
+
+// per-object frame layout remembered on the Python side (frame_len, symbols per frame)
+struct FrameLayout { int frame_len = 0; int nout = 0; };
+std::unordered_map<const void*, FrameLayout> g_layouts;
 
 } // namespace
 
@@ -130,6 +159,19 @@ PYBIND11_MODULE(gfdm_python, m)
         .def("cancel_sc_interference", [](receiver_kernel_cc& self, const carray td, const carray fd) {
             return rx_binary(self, td, fd, [&](cfloat* o, const cfloat* i, const cfloat* e) { self.cancel_sc_interference(o, i, e); });
         })
+        .def("configure_frames",
+             [](receiver_kernel_cc& self, int frame_len, int cp_len, std::vector<int> smap, bool per_timeslot) {
+                 self.configure_frames(frame_len, cp_len, smap, per_timeslot);
+                 g_layouts[&self] = FrameLayout{ frame_len, smap.empty() ? self.block_size() : static_cast<int>(smap.size()) * self.timeslots() };
+             },
+             py::arg("frame_len"), py::arg("cp_len"), py::arg("subcarrier_map") = std::vector<int>(), py::arg("per_timeslot") = true)
+        .def("demodulate_frames",
+             [](receiver_kernel_cc& self, const carray frames, py::object eq, int noutput_size) {
+                 const FrameLayout ly = g_layouts[&self];
+                 return run_frames(self, frames, eq, ly.frame_len, ly.nout, noutput_size);
+             },
+             py::arg("frames"), py::arg("f_eq") = py::none(), py::arg("noutput_size") = 0,
+             "cyclic-prefix removal + demodulation + resource demapping of whole frames in one kernel launch")
         .def("demodulate_batch",
              [](receiver_kernel_cc& self, const carray array, py::object eq) {
                  py::buffer_info in = array.request();
@@ -165,6 +207,18 @@ PYBIND11_MODULE(gfdm_python, m)
         .def("set_phase_compensation", &advanced_receiver_kernel_cc::set_phase_compensation)
         .def("get_phase_compensation", &advanced_receiver_kernel_cc::get_phase_compensation)
         .def("kernel_name", &advanced_receiver_kernel_cc::kernel_name)
+        .def("configure_frames",
+             [](advanced_receiver_kernel_cc& self, int frame_len, int cp_len, std::vector<int> smap, bool per_timeslot, int timeslots) {
+                 self.configure_frames(frame_len, cp_len, smap, per_timeslot);
+                 g_layouts[&self] = FrameLayout{ frame_len, smap.empty() ? self.block_size() : static_cast<int>(smap.size()) * timeslots };
+             },
+             py::arg("frame_len"), py::arg("cp_len"), py::arg("subcarrier_map"), py::arg("per_timeslot"), py::arg("timeslots"))
+        .def("demodulate_frames",
+             [](advanced_receiver_kernel_cc& self, const carray frames, py::object eq, int noutput_size) {
+                 const FrameLayout ly = g_layouts[&self];
+                 return run_frames(self, frames, eq, ly.frame_len, ly.nout, noutput_size);
+             },
+             py::arg("frames"), py::arg("f_eq") = py::none(), py::arg("noutput_size") = 0)
         .def("demodulate",
              [](advanced_receiver_kernel_cc& self, const carray array) {
                  py::buffer_info in = array.request();

@@ -110,3 +110,23 @@ def test_frames_device_path_and_errors():
     assert rec.shape == sym.shape
     assert float((rec - sym).abs().max()) < 0.2
     assert np.array_equal(adv.demodulate_frames(frames.cpu().numpy()), rec.cpu().numpy())
+
+
+def test_frames_pybind_surface():
+    """gfdm_python.Demodulator / AdvancedReceiver: configure_frames + demodulate_frames (C++ classes over the C-ABI)."""
+    import gfdm_python
+    g = load_tx_golden("tx_ref_k64_m9_cdd")
+    M, K, L = g["M"], g["K"], g["L"]
+    plen = g["preambles"].shape[1]
+    frames = g["pygfdm_frames"][0][:, plen:]
+    frame_len = g["cp"] + M * K + g["cs"]
+    dem = gfdm_python.Demodulator(M, K, L, g["taps"])
+    dem.configure_frames(frame_len, g["cp"], g["smap"].tolist(), True)
+    got = dem.demodulate_frames(frames)
+    assert got.shape == g["pygfdm_rx_symbols"].shape and got.dtype == np.complex64
+    assert_places(got, g["pygfdm_rx_symbols"], 5)
+    adv = gfdm_python.AdvancedReceiver(M, K, L, g["taps"], g["smap"].tolist(), 8, gfdm_python.Constellation.qpsk(), 0)
+    adv.configure_frames(frame_len, g["cp"], g["smap"].tolist(), True, M)
+    assert np.max(np.abs(adv.demodulate_frames(frames) - g["symbols"])) < 0.2
+    with pytest.raises(ValueError, match="unique"):
+        dem.configure_frames(frame_len, g["cp"], [1, 1, 2], True)
