@@ -86,19 +86,22 @@ template <int K, int M> struct RowTile {
 };
 
 // Row placement inside the tile WHILE the subcarrier FFT runs.  In natural order the autosort writes of the first radix-4
-// passes hit rows 4 tq + u resp. j + 16 qq + 4 u, whose b64 slots repeat every 4 lanes (4-way LDS bank conflict).  For
-// K = 64 the rows are therefore stored at slot sigma(row) = 16 c + 4 ((a + c) & 3) + ((b + c) & 3), row = 16 a + 4 b + c:
-// a Latin cube over the three radix-4 digits, so that every access pattern of every pass (and the row-per-lane write of
-// phase A) touches 16 different slots mod 16.  The LAST pass writes its output in natural order, which is what the
-// row-per-lane phases (equaliser, filter, IC, output) want.  Other K keep the natural order (correct, conflicted).
+// passes hit rows 4 tq + u resp. j + 16 qq + 4 u, whose b64 slots repeat every 4 lanes (4-way LDS bank conflict).  With the
+// low six row bits read as three radix-4 digits, row = 64 e + 16 b + 4 c + d, a group of 16 neighbouring lanes varies
+//   (c, d) in every pass read and in the row-per-lane write of phase A,   (b, c) in the pass-0 writes,   (b, d) in the pass-1 writes
+// (later passes vary (c, d) again).  The slot  64 e + 16 b + 4 ((c + b) & 3) + ((d + b) & 3)  is a bijection that stays
+// injective mod 16 on each of those digit pairs (and mod 32 on 32 consecutive rows), so none of these accesses has a bank
+// conflict.  The LAST pass writes natural order, which is what the row-per-lane phases (equaliser, filter, IC, output)
+// want.  K < 64 keeps the natural order (correct; several blocks share a wavefront there and the pattern differs).
 template <int K> struct FftLayout {
-    static __device__ __forceinline__ int slot(int row) { return row; }
-};
-template <> struct FftLayout<64> {
     static __device__ __forceinline__ int slot(int row)
     {
-        const int a = row >> 4, b = (row >> 2) & 3, c = row & 3;
-        return 16 * c + 4 * ((a + c) & 3) + ((b + c) & 3);
+        if constexpr (K >= 64) {
+            const int b = (row >> 4) & 3, c = (row >> 2) & 3, d = row & 3;
+            return (row & ~63) | (16 * b + 4 * ((c + b) & 3) + ((d + b) & 3));
+        } else {
+            return row;
+        }
     }
 };
 

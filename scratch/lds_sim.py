@@ -78,3 +78,17 @@ for var in range(6):
         print("variant", var, "pad", pad, "total", t)
 sg = make_sigma(0)
 print("detail variant 0"); evaluate(lambda row, m: sg(row) * 9 + m, True)
+
+print("---- generalised slot 64e + 16b + 4((c+b)&3) + ((d+b)&3), K=64")
+def slot(row):
+    b, c, d = (row >> 4) & 3, (row >> 2) & 3, row & 3
+    return (row & ~63) | (16 * b + 4 * ((c + b) & 3) + ((d + b) & 3))
+assert sorted(slot(r) for r in range(64)) == list(range(64))
+def addr_fft(row, m): return slot(row) * 9 + m
+# FFT-phase accesses use the slot layout, the row-per-lane phases natural order: evaluate the F*/A_w patterns with slot()
+tot = 0
+for name, rd, lst in patterns(addr_fft):
+    if name.startswith("F") or name == "A_w":
+        if name == "F2_w": lst = [l for n2, r2, l in [(n, r, l) for n, r, l in patterns(lambda row, m: row * 9 + m)] if n2 == "F2_w"][0]
+        c = sum(cost(a, rd) for a in lst); tot += c; print("  %-5s %4d" % (name, c))
+print("FFT-phase total", tot)
