@@ -341,6 +341,148 @@ __global__ __launch_bounds__(GT) void k_generic_cancel(DevicePlan p, cf* __restr
     cancel_rows(out + (int64_t)blockIdx.x * p.N, t0, fd + (int64_t)blockIdx.x * p.N, p);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Preamble channel estimator, one workgroup per received preamble (lib/preamble_channel_estimator_cc.cc):
+//   estimate_preamble_channel :118-145   K-point FFT of both preamble halves, times 0.5 / FFT(known half), summed
+//   filter_preamble_estimate  :147-187   active bins in fftshift order, DC interpolated when dc-free, 9-tap Gaussian
+//   interpolate_frame         :238-273   linear interpolation K bins -> M*K bins, written as a gather over the output
+//   prepare_for_zf            :275-281   conj(1 / x)
+// The whole chain stays in LDS: HBM sees the 2K input samples and the M*K output bins once.
+
+__device__ __forceinline__ cf est_filter_src(const cf* est, int u, const EstPlan& e)
+{
+    int v = u - 4;                                   // 4 = taps / 2 replicated edge bins on either side
+    v = v < 0 ? 0 : (v > e.n_est - 1 ? e.n_est - 1 : v);
+    const int half = e.A >> 1;
+    if (v < half) return est[e.K - half + v];
+    if (e.dc_free && v == half) {
+        const cf lo = est[e.K - 1], hi = est[1];
+        return make_float2(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y));
+    }
+    return est[v - half];                            // dc-free: bins 1.., else bins 0..
+}
+
+__global__ __launch_bounds__(GT) void k_estimate(EstPlan e, int in_stage, int out_stage, int zf, cf* __restrict__ out,
+                                                 const cf* __restrict__ in)
+{
+    extern __shared__ cf lds[];
+    const int K = e.K, n_est = e.n_est, M = e.M;
+    cf* a = lds;
+    cf* b = a + 2 * K;
+    cf* est = b + 2 * K;
+    cf* filt = est + K;
+    const int64_t f = blockIdx.x;
+    if (in_stage == EST_RX_PREAMBLE) {
+        const cf* rx = in + f * 2 * K;
+        for (int i = threadIdx.x; i < 2 * K; i += GT) {
+            const int h = i >= K, q = i - h * K;
+            a[q * 2 + h] = rx[i];                    // [q][half]: both halves go through one column FFT
+        }
+        __syncthreads();
+        DevicePlan p{};
+        p.M = 2; p.K = K; p.log2K = e.log2K; p.wK = e.wK;
+        const cf* E = col_fft<false>(a, b, p);
+        for (int j = threadIdx.x; j < K; j += GT) {
+            const cf v = cfma(E[2 * j], e.inv0[j], cmul(E[2 * j + 1], e.inv1[j]));
+            if (out_stage == EST_PREAMBLE_CHANNEL) out[f * K + j] = v; else est[j] = v;
+        }
+        if (out_stage == EST_PREAMBLE_CHANNEL) return;
+        __syncthreads();
+    } else if (in_stage == EST_PREAMBLE_CHANNEL) {
+        for (int j = threadIdx.x; j < K; j += GT) est[j] = in[f * K + j];
+        __syncthreads();
+    }
+    if (in_stage <= EST_PREAMBLE_CHANNEL) {
+        for (int i = threadIdx.x; i < n_est; i += GT) {
+            cf acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const cf v = est_filter_src(est, i + t, e);
+                acc.x += v.x * e.gauss[t];
+                acc.y += v.y * e.gauss[t];
+            }
+            if (out_stage == EST_FILTERED) out[f * n_est + i] = acc; else filt[i] = acc;
+        }
+        if (out_stage == EST_FILTERED) return;
+        __syncthreads();
+    } else {
+        for (int i = threadIdx.x; i < n_est; i += GT) filt[i] = in[f * n_est + i];
+        __syncthreads();
+    }
+    const int N = M * K, center = N / 2;
+    const int upper_segments = n_est - 1 - n_est / 2;      // bins [0, M * upper_segments): positive frequencies
+    const int low_start = center + M * (K - e.A) / 2;      // first negative-frequency bin that is interpolated
+    const float step = 1.0f / (float)M;
+    cf* o = out + f * N;
+    for (int n = threadIdx.x; n < N; n += GT) {
+        cf v;
+        int seg = -1, j = 0;
+        if (n < M * upper_segments) { seg = n_est / 2 + n / M; j = n % M; }
+        else if (n < center) v = filt[n_est - 1];
+        else if (n < low_start) v = filt[0];
+        else { seg = (n - low_start) / M; j = (n - low_start) % M; }
+        if (seg >= 0) {
+            const cf lo = filt[seg], hi = filt[seg + 1];
+            const float t = (float)j * step;
+            v = make_float2(lo.x + (hi.x - lo.x) * t, lo.y + (hi.y - lo.y) * t);
+        }
+        if (zf) v = cdiv(make_float2(1.f, 0.f), v), v.y = -v.y;
+        o[n] = v;
+    }
+}
+
+// estimate_snr :189-227 -- 2K-point FFT of the two-fold repeated preamble; even bins = symbol + noise, odd bins = noise.
+__global__ __launch_bounds__(GT) void k_estimate_snr(EstPlan e, float* __restrict__ snr, float* __restrict__ cnrs,
+                                                     const cf* __restrict__ in)
+{
+    extern __shared__ cf lds[];
+    __shared__ float red[2][GT];
+    const int K = e.K, A = e.A, half = e.A >> 1;
+    cf* a = lds;
+    cf* b = a + 2 * K;
+    const int64_t f = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * K; i += GT) a[i] = in[f * 2 * K + i];
+    __syncthreads();
+    DevicePlan p{};
+    p.M = 1; p.K = 2 * K; p.log2K = e.log2K2; p.wK = e.w2K;
+    const cf* S = col_fft<false>(a, b, p);
+    float* se_all = reinterpret_cast<float*>(S == a ? b : a);      // the idle tile keeps the per-bin symbol energies
+    float sym = 0.f, noise = 0.f;
+    for (int i = threadIdx.x; i < A; i += GT) {
+        const int bin = i < half ? i + (e.dc_free ? 1 : 0) : (i - half) + (K - A) / 2 + K / 2;
+        const cf s0 = S[2 * bin], s1 = S[2 * bin + 1];
+        const float se = s0.x * s0.x + s0.y * s0.y;
+        se_all[i] = se;
+        sym += se;
+        noise += s1.x * s1.x + s1.y * s1.y;
+    }
+    red[0][threadIdx.x] = sym;
+    red[1][threadIdx.x] = noise;
+    __syncthreads();
+    for (int w = GT / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    const float snr_lin = (red[0][0] - red[1][0]) / red[1][0];
+    const float scale = snr_lin / (red[0][0] / (float)A);
+    if (threadIdx.x == 0) snr[f] = snr_lin;
+    for (int i = threadIdx.x; i < A; i += GT) cnrs[f * A + i] = se_all[i] * scale;
+}
+
+__global__ __launch_bounds__(GT) void k_prepare_for_zf(cf* __restrict__ out, const cf* __restrict__ in, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * GT + threadIdx.x;
+    if (i < n) {
+        cf v = cdiv(make_float2(1.f, 0.f), in[i]);
+        v.y = -v.y;
+        out[i] = v;
+    }
+}
+
 constexpr size_t LDS_MAX = 160 * 1024;
 
 template <typename KernelT>
@@ -406,6 +548,37 @@ hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, con
     hipError_t e = allow_lds(k_generic_cancel, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_generic_cancel, dim3((unsigned)nblocks), dim3(GT), lds, s, p, out, td, fd);
+    return hipGetLastError();
+}
+
+size_t estimator_lds_bytes(int K) { return (size_t)(6 * K + 1) * sizeof(cf); }   // two [K][2] tiles, K-bin estimate, smoothed estimate
+
+bool estimator_supports(int K) { return estimator_lds_bytes(K) <= LDS_MAX; }
+
+hipError_t launch_estimate(const EstPlan& e, int in_stage, int out_stage, int zf, cf* out, const cf* in, int64_t nframes, hipStream_t s)
+{
+    if (nframes <= 0) return hipSuccess;
+    const size_t lds = estimator_lds_bytes(e.K);
+    hipError_t err = allow_lds(k_estimate, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_estimate, dim3((unsigned)nframes), dim3(GT), lds, s, e, in_stage, out_stage, zf, out, in);
+    return hipGetLastError();
+}
+
+hipError_t launch_estimate_snr(const EstPlan& e, float* snr, float* cnrs, const cf* in, int64_t nframes, hipStream_t s)
+{
+    if (nframes <= 0) return hipSuccess;
+    const size_t lds = (size_t)4 * e.K * sizeof(cf);
+    hipError_t err = allow_lds(k_estimate_snr, lds);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_estimate_snr, dim3((unsigned)nframes), dim3(GT), lds, s, e, snr, cnrs, in);
+    return hipGetLastError();
+}
+
+hipError_t launch_prepare_for_zf(cf* out, const cf* in, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prepare_for_zf, dim3((unsigned)((n + GT - 1) / GT)), dim3(GT), 0, s, out, in, n);
     return hipGetLastError();
 }
 

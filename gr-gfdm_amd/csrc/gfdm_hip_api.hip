@@ -6,6 +6,8 @@
 #include "gfdm_tx.h"
 
 #include <cmath>
+#include <complex>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -905,6 +907,237 @@ int gfdm_hip_transmitter_add_frame_host(gfdm_hip_transmitter* t, float* out, con
     return tx_host(t, outs, 1, (size_t)t->tx.F, in, (size_t)t->plan.dp.N, nblocks, [&](void* const* d_outs, const void* d_in, hipStream_t s) {
         return gfdm_hip_transmitter_add_frame_device(t, d_outs[0], d_in, cyclic_shift, nblocks, (void*)s);
     });
+}
+
+}  // extern "C"
+
+// ---- preamble channel estimator (lib/preamble_channel_estimator_cc.cc) ----------------------------------------------
+
+struct gfdm_hip_channel_estimator {
+    Plan plan;                       // device, private stream, staging buffers, table allocation (plan.dp is unused)
+    gfdm::EstPlan ep{};
+    int which_estimator = 0;
+};
+
+namespace {
+
+// plain O(K^2) DFT in double: constructor-time only (the reference runs FFTW here, :99-107)
+void host_dft(std::vector<std::complex<double>>& out, const float* in, int K)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    out.assign(K, std::complex<double>(0.0, 0.0));
+    std::vector<std::complex<double>> w(K);
+    for (int i = 0; i < K; ++i) w[i] = std::complex<double>(std::cos(two_pi * i / K), -std::sin(two_pi * i / K));
+    for (int j = 0; j < K; ++j) {
+        std::complex<double> acc(0.0, 0.0);
+        int e = 0;
+        for (int q = 0; q < K; ++q) {
+            acc += std::complex<double>(in[2 * q], in[2 * q + 1]) * w[e];
+            e += j;
+            if (e >= K) e -= K;
+        }
+        out[j] = acc;
+    }
+}
+
+int est_stage_elems(const gfdm::EstPlan& e, int stage)
+{
+    switch (stage) {
+    case gfdm::EST_RX_PREAMBLE: return 2 * e.K;
+    case gfdm::EST_PREAMBLE_CHANNEL: return e.K;
+    case gfdm::EST_FILTERED: return e.n_est;
+    default: return e.M * e.K;
+    }
+}
+
+int est_run_device(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, int zf, void* out, const void* in, int64_t nframes, void* stream)
+{
+    if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    return run_device(c->plan, out, in, nframes, [&]() {
+        return gfdm::launch_estimate(c->ep, in_stage, out_stage, zf, static_cast<cf*>(out), static_cast<const cf*>(in), nframes,
+                                     static_cast<hipStream_t>(stream));
+    });
+}
+
+int est_run_host(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, int zf, float* out, const float* in, int64_t nframes)
+{
+    if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    if (nframes < 0) return fail(GFDM_HIP_EINVAL, "negative frame count");
+    const size_t nout = (size_t)nframes * est_stage_elems(c->ep, out_stage), nin = (size_t)nframes * est_stage_elems(c->ep, in_stage);
+    return run_host_sized(c->plan, out, nout, in, nin, nullptr, 0, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
+        return gfdm::launch_estimate(c->ep, in_stage, out_stage, zf, o, i, nframes, s);
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfdm_hip_channel_estimator_create(gfdm_hip_channel_estimator** out, int timeslots, int fft_len, int active_subcarriers, int is_dc_free,
+                                      int which_estimator, const float* preamble, int n_preamble, int device)
+{
+    if (!out) return fail(GFDM_HIP_EINVAL, "NULL output handle");
+    *out = nullptr;
+    if (timeslots < 1 || fft_len < 2 || active_subcarriers < 2 || active_subcarriers > fft_len - (is_dc_free ? 1 : 0) || (active_subcarriers & 1) ||
+        preamble == nullptr)
+        return fail(GFDM_HIP_EINVAL, "timeslots >= 1, fft_len >= 2, even 2 <= active_subcarriers <= fft_len (fft_len - 1 when dc-free), preamble non-NULL");
+    if (n_preamble < 2 * fft_len) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "preamble holds %d samples, MUST hold 2 * fft_len = %d", n_preamble, 2 * fft_len);
+        return fail(GFDM_HIP_EINVAL, buf);
+    }
+    if (!gfdm::estimator_supports(fft_len)) return fail(GFDM_HIP_EUNSUPPORTED, "fft_len too large for the LDS-resident estimator");
+    std::unique_ptr<gfdm_hip_channel_estimator> c(new gfdm_hip_channel_estimator);
+    const int K = fft_len;
+    c->plan.device = device;
+    c->which_estimator = which_estimator;
+    std::vector<cf> tables;                                            // inv0 | inv1 | wK | w2K
+    tables.reserve(5 * (size_t)K);
+    std::vector<std::complex<double>> fd;
+    for (int h = 0; h < 2; ++h) {
+        host_dft(fd, preamble + 2 * (size_t)h * K, K);
+        for (int j = 0; j < K; ++j) {                                  // initialize_inv_freq_preamble :108-116
+            const std::complex<double> v = std::complex<double>(0.5, 0.0) / fd[j];
+            tables.push_back(make_float2((float)v.real(), (float)v.imag()));
+        }
+    }
+    unit_roots(tables, K);
+    unit_roots(tables, 2 * K);
+    gfdm::EstPlan& e = c->ep;
+    e.M = timeslots; e.K = K; e.A = active_subcarriers; e.dc_free = is_dc_free ? 1 : 0;
+    e.n_est = active_subcarriers + e.dc_free;
+    e.log2K = ilog2_exact(K);
+    e.log2K2 = ilog2_exact(2 * K);
+    float sum = 0.0f;                                                  // initialize_gaussian_filter :84-97 (float arithmetic)
+    for (int i = 0; i < 9; ++i) { e.gauss[i] = std::exp(-0.5f * (float)((i - 4) * (i - 4))); sum += e.gauss[i]; }
+    for (int i = 0; i < 9; ++i) e.gauss[i] /= sum;
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
+    HIP_TRY(hipMalloc(&c->plan.d_tables, tables.size() * sizeof(cf)));
+    HIP_TRY(hipMemcpy(c->plan.d_tables, tables.data(), tables.size() * sizeof(cf), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamCreateWithFlags(&c->plan.stream, hipStreamNonBlocking));
+    e.inv0 = c->plan.d_tables;
+    e.inv1 = e.inv0 + K;
+    e.wK = e.inv1 + K;
+    e.w2K = e.wK + K;
+    c->plan.kernel_name = "generic_lds";
+    *out = c.release();
+    return GFDM_HIP_OK;
+}
+
+int gfdm_hip_channel_estimator_destroy(gfdm_hip_channel_estimator* c) { delete c; return GFDM_HIP_OK; }
+int gfdm_hip_channel_estimator_timeslots(const gfdm_hip_channel_estimator* c) { return c ? c->ep.M : GFDM_HIP_EINVAL; }
+int gfdm_hip_channel_estimator_fft_len(const gfdm_hip_channel_estimator* c) { return c ? c->ep.K : GFDM_HIP_EINVAL; }
+int gfdm_hip_channel_estimator_active_subcarriers(const gfdm_hip_channel_estimator* c) { return c ? c->ep.A : GFDM_HIP_EINVAL; }
+int gfdm_hip_channel_estimator_frame_len(const gfdm_hip_channel_estimator* c) { return c ? c->ep.M * c->ep.K : GFDM_HIP_EINVAL; }
+int gfdm_hip_channel_estimator_is_dc_free(const gfdm_hip_channel_estimator* c) { return c ? c->ep.dc_free : GFDM_HIP_EINVAL; }
+int gfdm_hip_channel_estimator_filtered_len(const gfdm_hip_channel_estimator* c) { return c ? c->ep.n_est : GFDM_HIP_EINVAL; }
+
+int gfdm_hip_channel_estimator_preamble_filter_taps(const gfdm_hip_channel_estimator* c, float* out)
+{
+    if (!c || !out) return fail(GFDM_HIP_EINVAL, "NULL argument");
+    memcpy(out, c->ep.gauss, sizeof c->ep.gauss);
+    return 9;
+}
+
+int gfdm_hip_channel_estimator_estimate_frame_device(gfdm_hip_channel_estimator* c, void* frame_estimate, const void* rx_preamble,
+                                                     int64_t nframes, void* stream)
+{
+    return est_run_device(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_FRAME, 0, frame_estimate, rx_preamble, nframes, stream);
+}
+
+int gfdm_hip_channel_estimator_estimate_frame_host(gfdm_hip_channel_estimator* c, float* frame_estimate, const float* rx_preamble, int64_t nframes)
+{
+    return est_run_host(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_FRAME, 0, frame_estimate, rx_preamble, nframes);
+}
+
+int gfdm_hip_channel_estimator_estimate_preamble_channel_device(gfdm_hip_channel_estimator* c, void* fd_preamble_channel, const void* rx_preamble,
+                                                                int64_t nframes, void* stream)
+{
+    return est_run_device(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_PREAMBLE_CHANNEL, 0, fd_preamble_channel, rx_preamble, nframes, stream);
+}
+
+int gfdm_hip_channel_estimator_estimate_preamble_channel_host(gfdm_hip_channel_estimator* c, float* fd_preamble_channel, const float* rx_preamble,
+                                                              int64_t nframes)
+{
+    return est_run_host(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_PREAMBLE_CHANNEL, 0, fd_preamble_channel, rx_preamble, nframes);
+}
+
+int gfdm_hip_channel_estimator_filter_preamble_estimate_device(gfdm_hip_channel_estimator* c, void* filtered, const void* estimate, int64_t nframes,
+                                                               void* stream)
+{
+    return est_run_device(c, gfdm::EST_PREAMBLE_CHANNEL, gfdm::EST_FILTERED, 0, filtered, estimate, nframes, stream);
+}
+
+int gfdm_hip_channel_estimator_filter_preamble_estimate_host(gfdm_hip_channel_estimator* c, float* filtered, const float* estimate, int64_t nframes)
+{
+    return est_run_host(c, gfdm::EST_PREAMBLE_CHANNEL, gfdm::EST_FILTERED, 0, filtered, estimate, nframes);
+}
+
+int gfdm_hip_channel_estimator_interpolate_frame_device(gfdm_hip_channel_estimator* c, void* frame_estimate, const void* filtered, int64_t nframes,
+                                                        void* stream)
+{
+    return est_run_device(c, gfdm::EST_FILTERED, gfdm::EST_FRAME, 0, frame_estimate, filtered, nframes, stream);
+}
+
+int gfdm_hip_channel_estimator_interpolate_frame_host(gfdm_hip_channel_estimator* c, float* frame_estimate, const float* filtered, int64_t nframes)
+{
+    return est_run_host(c, gfdm::EST_FILTERED, gfdm::EST_FRAME, 0, frame_estimate, filtered, nframes);
+}
+
+int gfdm_hip_channel_estimator_prepare_for_zf_device(gfdm_hip_channel_estimator* c, void* transformed_frame, const void* frame_estimate,
+                                                     int64_t nframes, void* stream)
+{
+    if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    return run_device(c->plan, transformed_frame, frame_estimate, nframes, [&]() {
+        return gfdm::launch_prepare_for_zf(static_cast<cf*>(transformed_frame), static_cast<const cf*>(frame_estimate),
+                                           nframes * c->ep.M * c->ep.K, static_cast<hipStream_t>(stream));
+    });
+}
+
+int gfdm_hip_channel_estimator_prepare_for_zf_host(gfdm_hip_channel_estimator* c, float* transformed_frame, const float* frame_estimate,
+                                                   int64_t nframes)
+{
+    if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    if (nframes < 0) return fail(GFDM_HIP_EINVAL, "negative frame count");
+    const size_t n = (size_t)nframes * c->ep.M * c->ep.K;
+    return run_host_sized(c->plan, transformed_frame, n, frame_estimate, n, nullptr, 0, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
+        return gfdm::launch_prepare_for_zf(o, i, (int64_t)n, s);
+    });
+}
+
+int gfdm_hip_channel_estimator_estimate_snr_device(gfdm_hip_channel_estimator* c, float* snr_lin, float* cnrs, const void* rx_preamble,
+                                                   int64_t nframes, void* stream)
+{
+    if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    if (!cnrs) return fail(GFDM_HIP_EINVAL, "NULL buffer");
+    return run_device(c->plan, snr_lin, rx_preamble, nframes, [&]() {
+        return gfdm::launch_estimate_snr(c->ep, snr_lin, cnrs, static_cast<const cf*>(rx_preamble), nframes, static_cast<hipStream_t>(stream));
+    });
+}
+
+int gfdm_hip_channel_estimator_estimate_snr_host(gfdm_hip_channel_estimator* c, float* snr_lin, float* cnrs, const float* rx_preamble, int64_t nframes)
+{
+    if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    if (nframes < 0 || !snr_lin || !cnrs || !rx_preamble) return fail(GFDM_HIP_EINVAL, "NULL buffer or negative frame count");
+    if (nframes == 0) return GFDM_HIP_OK;
+    Plan& pl = c->plan;
+    DeviceGuard guard(pl.device);
+    if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
+    const size_t A = (size_t)c->ep.A, nin = (size_t)nframes * 2 * c->ep.K;
+    const size_t nfloats = (size_t)nframes * (A + 1);                 // snr[nframes] | cnrs[nframes][A], staged as floats
+    int rc;
+    if ((rc = ensure_stage(pl, 0, (nfloats + 1) / 2)) != GFDM_HIP_OK) return rc;
+    if ((rc = ensure_stage(pl, 1, nin)) != GFDM_HIP_OK) return rc;
+    float* d_snr = reinterpret_cast<float*>(pl.stage[0]);
+    float* d_cnrs = d_snr + nframes;
+    HIP_TRY(hipMemcpyAsync(pl.stage[1], rx_preamble, nin * sizeof(cf), hipMemcpyHostToDevice, pl.stream));
+    hipError_t e = gfdm::launch_estimate_snr(c->ep, d_snr, d_cnrs, pl.stage[1], nframes, pl.stream);
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    HIP_TRY(hipMemcpyAsync(snr_lin, d_snr, (size_t)nframes * sizeof(float), hipMemcpyDeviceToHost, pl.stream));
+    HIP_TRY(hipMemcpyAsync(cnrs, d_cnrs, (size_t)nframes * A * sizeof(float), hipMemcpyDeviceToHost, pl.stream));
+    HIP_TRY(hipStreamSynchronize(pl.stream));
+    return GFDM_HIP_OK;
 }
 
 }  // extern "C"

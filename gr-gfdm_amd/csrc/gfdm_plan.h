@@ -85,6 +85,27 @@ hipError_t launch_rowlane_modulate(const DevicePlan& p, const TxParams& tx, cons
 hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in,
                                   const cf* f_eq, int64_t nblocks, hipStream_t s);
 
+// Preamble channel estimator (lib/preamble_channel_estimator_cc.cc): tables of one estimator handle.
+struct EstPlan {
+    int M, K, A;          // timeslots, fft_len (subcarriers), active subcarriers
+    int dc_free;
+    int n_est;            // A + dc_free: bins of the smoothed estimate
+    int log2K, log2K2;    // log2 of K and 2K, or -1: direct DFT
+    const cf* inv0;       // [K]  0.5 / FFT_K(preamble first half)
+    const cf* inv1;       // [K]  0.5 / FFT_K(preamble second half)
+    const cf* wK;         // [K]  exp(-2 pi i j / K)
+    const cf* w2K;        // [2K] exp(-2 pi i j / 2K)
+    float gauss[9];       // normalised Gaussian smoothing taps (sigma^2 = 1)
+};
+
+// stages of the estimator chain; a launch runs in_stage -> out_stage inside one kernel
+enum EstStage { EST_RX_PREAMBLE = 0, EST_PREAMBLE_CHANNEL = 1, EST_FILTERED = 2, EST_FRAME = 3 };
+size_t estimator_lds_bytes(int K);
+bool estimator_supports(int K);
+hipError_t launch_estimate(const EstPlan& e, int in_stage, int out_stage, int zf, cf* out, const cf* in, int64_t nframes, hipStream_t s);
+hipError_t launch_estimate_snr(const EstPlan& e, float* snr, float* cnrs, const cf* in, int64_t nframes, hipStream_t s);
+hipError_t launch_prepare_for_zf(cf* out, const cf* in, int64_t n, hipStream_t s);
+
 enum KernelFamily { FAMILY_GENERIC = 0, FAMILY_FAST = 1, FAMILY_ROWLANE = 2 };
 
 }  // namespace gfdm

@@ -10,6 +10,7 @@
 #include <gfdm/advanced_receiver_kernel_cc.h>
 #include <gfdm/modulator_kernel_cc.h>
 #include <gfdm/receiver_kernel_cc.h>
+#include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm/transmitter_kernel.h>
 
 #include <unordered_map>
@@ -270,4 +271,53 @@ PYBIND11_MODULE(gfdm_python, m)
              },
              py::arg("symbols"), py::arg("n_ports") = 0,
              "frames of every cyclic shift (list of arrays [nframes, output_vector_size]) for nframes * input_vector_size symbols");
+
+    // python/bindings/preamble_channel_estimator_python.cc:30-99 (same class name, constructor arguments, methods, messages);
+    // estimate_frame / estimate_snr additionally accept [nframes][2 * subcarriers] batches, estimate_snr_cnrs returns the
+    // per-subcarrier CNRs the reference computes but drops at the binding (:94-97)
+    py::class_<preamble_channel_estimator_cc>(m, "Preamble_channel_estimator")
+        .def(py::init<int, int, int, bool, int, std::vector<cfloat>>(), py::arg("timeslots"), py::arg("subcarriers"),
+             py::arg("active_subcarriers"), py::arg("is_dc_free"), py::arg("which_estimator"), py::arg("preamble"))
+        .def("timeslots", &preamble_channel_estimator_cc::timeslots)
+        .def("subcarriers", &preamble_channel_estimator_cc::fft_len)
+        .def("active_subcarriers", &preamble_channel_estimator_cc::active_subcarriers)
+        .def("frame_len", &preamble_channel_estimator_cc::frame_len)
+        .def("is_dc_free", &preamble_channel_estimator_cc::is_dc_free)
+        .def("preamble_filter_taps", &preamble_channel_estimator_cc::preamble_filter_taps)
+        .def("estimate_frame",
+             [](preamble_channel_estimator_cc& self, const carray array) {
+                 py::buffer_info in = array.request();
+                 const py::ssize_t n = 2 * self.fft_len();
+                 if (in.ndim > 2) throw std::runtime_error("Only ONE-dimensional vectors allowed!");
+                 if ((in.ndim == 1 && in.size != n) || (in.ndim == 2 && in.shape[1] != n))
+                     throw std::runtime_error("Input vector size(" + std::to_string(in.ndim == 2 ? in.shape[1] : in.size) +
+                                              ") MUST be equal to 2 * subcarriers(" + std::to_string(n) + ")!");
+                 const long nframes = in.ndim == 2 ? static_cast<long>(in.shape[0]) : 1;
+                 auto result = in.ndim == 2 ? py::array_t<cfloat>(std::vector<py::ssize_t>{ nframes, self.frame_len() })
+                                            : py::array_t<cfloat>(self.frame_len());
+                 py::buffer_info out = result.request();
+                 self.estimate_frame_batch(ptr(out), cptr(in), nframes);
+                 return result;
+             })
+        .def("estimate_snr",
+             [](preamble_channel_estimator_cc& self, const carray array) {
+                 py::buffer_info in = array.request();
+                 if (in.ndim != 1) throw std::runtime_error("Only ONE-dimensional vectors allowed!");
+                 if (in.size != 2 * self.fft_len())
+                     throw std::runtime_error("Input vector size(" + std::to_string(in.size) + ") MUST be equal to 2 * subcarriers(" +
+                                              std::to_string(2 * self.fft_len()) + ")!");
+                 std::vector<float> cnrs;
+                 return self.estimate_snr(cnrs, cptr(in));
+             })
+        .def("estimate_snr_cnrs", [](preamble_channel_estimator_cc& self, const carray array) {
+            py::buffer_info in = array.request();
+            const py::ssize_t n = 2 * self.fft_len();
+            if (in.size == 0 || in.size % n)
+                throw std::runtime_error("Input size(" + std::to_string(in.size) + ") MUST be a multiple of 2 * subcarriers(" + std::to_string(n) + ")!");
+            const long nframes = in.size / n;
+            py::array_t<float> snr(nframes);
+            py::array_t<float> cnrs(std::vector<py::ssize_t>{ nframes, self.active_subcarriers() });
+            self.estimate_snr_batch(static_cast<float*>(snr.request().ptr), static_cast<float*>(cnrs.request().ptr), cptr(in), nframes);
+            return py::make_tuple(snr, cnrs);
+        });
 }

@@ -34,6 +34,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `make -C gr-gfdm_amd` (no CPU fallback exists)" % LIB_PATH)
+    # PyTorch-ROCm ships its own copy of the HIP runtime (torch/lib/libamdhip64.so).  A process can only work with ONE runtime:
+    # if /opt/rocm's gets initialised first (through this library), torch later reports "No HIP GPUs are available".  The device
+    # path of this package hands torch tensors to the library, so when torch is installed its runtime is loaded first and
+    # libgfdm_hip.so binds to it (same SONAME); without torch the library uses /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_char_p
     sig = {
@@ -95,6 +103,27 @@ def lib():
         "gfdm_hip_transmitter_modulate_device": (i32, [vp, vp, vp, i32, i64, vp]),
         "gfdm_hip_transmitter_add_frame_host": (i32, [vp, vp, vp, i32, i64]),
         "gfdm_hip_transmitter_add_frame_device": (i32, [vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_channel_estimator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, i32, i32, vp, i32, i32]),
+        "gfdm_hip_channel_estimator_destroy": (i32, [vp]),
+        "gfdm_hip_channel_estimator_timeslots": (i32, [vp]),
+        "gfdm_hip_channel_estimator_fft_len": (i32, [vp]),
+        "gfdm_hip_channel_estimator_active_subcarriers": (i32, [vp]),
+        "gfdm_hip_channel_estimator_frame_len": (i32, [vp]),
+        "gfdm_hip_channel_estimator_is_dc_free": (i32, [vp]),
+        "gfdm_hip_channel_estimator_filtered_len": (i32, [vp]),
+        "gfdm_hip_channel_estimator_preamble_filter_taps": (i32, [vp, vp]),
+        "gfdm_hip_channel_estimator_estimate_frame_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_channel_estimator_estimate_frame_device": (i32, [vp, vp, vp, i64, vp]),
+        "gfdm_hip_channel_estimator_estimate_preamble_channel_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_channel_estimator_estimate_preamble_channel_device": (i32, [vp, vp, vp, i64, vp]),
+        "gfdm_hip_channel_estimator_filter_preamble_estimate_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_channel_estimator_filter_preamble_estimate_device": (i32, [vp, vp, vp, i64, vp]),
+        "gfdm_hip_channel_estimator_interpolate_frame_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_channel_estimator_interpolate_frame_device": (i32, [vp, vp, vp, i64, vp]),
+        "gfdm_hip_channel_estimator_prepare_for_zf_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_channel_estimator_prepare_for_zf_device": (i32, [vp, vp, vp, i64, vp]),
+        "gfdm_hip_channel_estimator_estimate_snr_host": (i32, [vp, vp, vp, vp, i64]),
+        "gfdm_hip_channel_estimator_estimate_snr_device": (i32, [vp, vp, vp, vp, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == the library does not export a declared symbol
@@ -486,3 +515,108 @@ class Transmitter(_Kernel):
         out = np.empty((nb, F), np.complex64)
         _check(L.gfdm_hip_transmitter_add_frame_host(self._h, out.ctypes.data, x.ctypes.data, int(cyclic_shift), nb))
         return out
+
+
+class ChannelEstimator(_Kernel):
+    """preamble_channel_estimator_cc (include/gfdm/preamble_channel_estimator_cc.h:45-78; pybind name
+    Preamble_channel_estimator, python/bindings/preamble_channel_estimator_python.cc): received preamble -> frame channel
+    estimate.  Every call takes one preamble / estimate or a batch of them ([nframes][len]); numpy in -> numpy out (host path),
+    torch in -> torch out (device path, current stream unless given)."""
+    _destroy = "gfdm_hip_channel_estimator_destroy"
+
+    def __init__(self, timeslots, fft_len, active_subcarriers, is_dc_free, which_estimator, preamble, device=0):
+        L = lib()
+        p = _c64(preamble).ravel()
+        h = ctypes.c_void_p()
+        _check(L.gfdm_hip_channel_estimator_create(ctypes.byref(h), timeslots, fft_len, active_subcarriers, int(bool(is_dc_free)),
+                                                   int(which_estimator), p.ctypes.data, p.size, device))
+        self._h = h
+
+    def timeslots(self):
+        return lib().gfdm_hip_channel_estimator_timeslots(self._h)
+
+    def fft_len(self):
+        return lib().gfdm_hip_channel_estimator_fft_len(self._h)
+
+    subcarriers = fft_len                   # the pybind property is called `subcarriers` (preamble_channel_estimator_python.cc:52)
+
+    def active_subcarriers(self):
+        return lib().gfdm_hip_channel_estimator_active_subcarriers(self._h)
+
+    def frame_len(self):
+        return lib().gfdm_hip_channel_estimator_frame_len(self._h)
+
+    def is_dc_free(self):
+        return bool(lib().gfdm_hip_channel_estimator_is_dc_free(self._h))
+
+    def filtered_len(self):
+        return lib().gfdm_hip_channel_estimator_filtered_len(self._h)
+
+    def preamble_filter_taps(self):
+        out = np.empty(9, np.float32)
+        lib().gfdm_hip_channel_estimator_preamble_filter_taps(self._h, out.ctypes.data)
+        return out
+
+    def _lens(self):
+        return {"rx": 2 * self.fft_len(), "est": self.fft_len(), "filt": self.filtered_len(), "frame": self.frame_len()}
+
+    def _run(self, name, x, n_in, n_out, stream):
+        L = lib()
+        if _is_tensor(x):
+            import torch
+            if x.numel() % n_in:
+                raise RuntimeError("Input size %d is not a multiple of %d" % (x.numel(), n_in))
+            nf = x.numel() // n_in
+            out = torch.empty((nf, n_out) if x.dim() > 1 or nf != 1 else (n_out,), dtype=torch.complex64, device=x.device)
+            _check(getattr(L, name + "_device")(self._h, out.data_ptr(), _dev_ptr(x, nf * n_in, "in"), nf, _stream_ptr(stream)))
+            return out
+        a = _c64(x)
+        if a.size % n_in:
+            raise RuntimeError("Input size %d is not a multiple of %d" % (a.size, n_in))
+        nf = a.size // n_in
+        out = np.empty((nf, n_out) if a.ndim > 1 or nf != 1 else (n_out,), np.complex64)
+        _check(getattr(L, name + "_host")(self._h, out.ctypes.data, a.ctypes.data, nf))
+        return out
+
+    def estimate_frame(self, rx_preamble, stream=None):
+        n = self._lens()
+        return self._run("gfdm_hip_channel_estimator_estimate_frame", rx_preamble, n["rx"], n["frame"], stream)
+
+    def estimate_preamble_channel(self, rx_preamble, stream=None):
+        n = self._lens()
+        return self._run("gfdm_hip_channel_estimator_estimate_preamble_channel", rx_preamble, n["rx"], n["est"], stream)
+
+    def filter_preamble_estimate(self, estimate, stream=None):
+        n = self._lens()
+        return self._run("gfdm_hip_channel_estimator_filter_preamble_estimate", estimate, n["est"], n["filt"], stream)
+
+    def interpolate_frame(self, filtered, stream=None):
+        n = self._lens()
+        return self._run("gfdm_hip_channel_estimator_interpolate_frame", filtered, n["filt"], n["frame"], stream)
+
+    def prepare_for_zf(self, frame_estimate, stream=None):
+        n = self._lens()
+        return self._run("gfdm_hip_channel_estimator_prepare_for_zf", frame_estimate, n["frame"], n["frame"], stream)
+
+    def estimate_snr(self, rx_preamble, stream=None):
+        """(snr_lin, cnrs): scalars / [active] for one preamble, [nframes] / [nframes][active] for a batch."""
+        L = lib()
+        n_in, A = 2 * self.fft_len(), self.active_subcarriers()
+        if _is_tensor(rx_preamble):
+            import torch
+            nf = rx_preamble.numel() // n_in
+            snr = torch.empty(nf, dtype=torch.float32, device=rx_preamble.device)
+            cnrs = torch.empty(nf, A, dtype=torch.float32, device=rx_preamble.device)
+            _check(L.gfdm_hip_channel_estimator_estimate_snr_device(self._h, snr.data_ptr(), cnrs.data_ptr(), _dev_ptr(rx_preamble, nf * n_in, "in"),
+                                                                    nf, _stream_ptr(stream)))
+            return snr, cnrs
+        a = _c64(rx_preamble)
+        if a.size % n_in:
+            raise RuntimeError("Input size %d is not a multiple of %d" % (a.size, n_in))
+        nf = a.size // n_in
+        snr = np.empty(nf, np.float32)
+        cnrs = np.empty((nf, A), np.float32)
+        _check(L.gfdm_hip_channel_estimator_estimate_snr_host(self._h, snr.ctypes.data, cnrs.ctypes.data, a.ctypes.data, nf))
+        if a.ndim <= 1 and nf == 1:
+            return float(snr[0]), cnrs[0]
+        return snr, cnrs

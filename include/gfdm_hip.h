@@ -178,6 +178,51 @@ int gfdm_hip_transmitter_modulate_device(gfdm_hip_transmitter* t, void* out, con
 int gfdm_hip_transmitter_add_frame_host(gfdm_hip_transmitter* t, float* out, const float* in, int cyclic_shift, int64_t nblocks);
 int gfdm_hip_transmitter_add_frame_device(gfdm_hip_transmitter* t, void* out, const void* in, int cyclic_shift, int64_t nblocks, void* stream);
 
+/* ---- preamble_channel_estimator_cc (include/gfdm/preamble_channel_estimator_cc.h:45-78) ----
+ * Received preamble (2 * fft_len samples) -> frequency-domain channel estimate of a whole frame (timeslots * fft_len bins), the
+ * f_eq input of the receivers above.  One HIP kernel per call, one workgroup per preamble, every stage LDS-resident;
+ * `nframes` preambles / estimates back to back. */
+typedef struct gfdm_hip_channel_estimator gfdm_hip_channel_estimator;
+
+/* ctor, lib/preamble_channel_estimator_cc.cc:32-76.  preamble: n_preamble >= 2 * fft_len complex (the known core preamble). */
+int gfdm_hip_channel_estimator_create(gfdm_hip_channel_estimator** out, int timeslots, int fft_len, int active_subcarriers, int is_dc_free,
+                                      int which_estimator, const float* preamble, int n_preamble, int device);
+int gfdm_hip_channel_estimator_destroy(gfdm_hip_channel_estimator* c);
+int gfdm_hip_channel_estimator_timeslots(const gfdm_hip_channel_estimator* c);            /* .h:58 */
+int gfdm_hip_channel_estimator_fft_len(const gfdm_hip_channel_estimator* c);              /* .h:57 */
+int gfdm_hip_channel_estimator_active_subcarriers(const gfdm_hip_channel_estimator* c);   /* .h:60 */
+int gfdm_hip_channel_estimator_frame_len(const gfdm_hip_channel_estimator* c);            /* .h:59, timeslots * fft_len */
+int gfdm_hip_channel_estimator_is_dc_free(const gfdm_hip_channel_estimator* c);           /* .h:61 */
+int gfdm_hip_channel_estimator_filtered_len(const gfdm_hip_channel_estimator* c);         /* active_subcarriers + is_dc_free */
+int gfdm_hip_channel_estimator_preamble_filter_taps(const gfdm_hip_channel_estimator* c, float* out);   /* .h:62, 9 floats; returns 9 */
+/* estimate_frame (lib/preamble_channel_estimator_cc.cc:284-295): the three stages below fused.  Bins the reference leaves
+ * unwritten when not dc-free ([(A/2 - 1) M, (A/2) M)) carry the value of the constant region next to them. */
+int gfdm_hip_channel_estimator_estimate_frame_host(gfdm_hip_channel_estimator* c, float* frame_estimate, const float* rx_preamble, int64_t nframes);
+int gfdm_hip_channel_estimator_estimate_frame_device(gfdm_hip_channel_estimator* c, void* frame_estimate, const void* rx_preamble,
+                                                     int64_t nframes, void* stream);
+/* estimate_preamble_channel (:118-145): rx preamble -> fft_len bins */
+int gfdm_hip_channel_estimator_estimate_preamble_channel_host(gfdm_hip_channel_estimator* c, float* fd_preamble_channel, const float* rx_preamble,
+                                                              int64_t nframes);
+int gfdm_hip_channel_estimator_estimate_preamble_channel_device(gfdm_hip_channel_estimator* c, void* fd_preamble_channel, const void* rx_preamble,
+                                                                int64_t nframes, void* stream);
+/* filter_preamble_estimate (:147-187): fft_len bins -> filtered_len smoothed bins (fftshift order) */
+int gfdm_hip_channel_estimator_filter_preamble_estimate_host(gfdm_hip_channel_estimator* c, float* filtered, const float* estimate, int64_t nframes);
+int gfdm_hip_channel_estimator_filter_preamble_estimate_device(gfdm_hip_channel_estimator* c, void* filtered, const void* estimate, int64_t nframes,
+                                                               void* stream);
+/* interpolate_frame (:238-273): filtered_len bins -> frame_len bins */
+int gfdm_hip_channel_estimator_interpolate_frame_host(gfdm_hip_channel_estimator* c, float* frame_estimate, const float* filtered, int64_t nframes);
+int gfdm_hip_channel_estimator_interpolate_frame_device(gfdm_hip_channel_estimator* c, void* frame_estimate, const void* filtered, int64_t nframes,
+                                                        void* stream);
+/* prepare_for_zf (:275-281): conj(1 / frame_estimate) */
+int gfdm_hip_channel_estimator_prepare_for_zf_host(gfdm_hip_channel_estimator* c, float* transformed_frame, const float* frame_estimate,
+                                                   int64_t nframes);
+int gfdm_hip_channel_estimator_prepare_for_zf_device(gfdm_hip_channel_estimator* c, void* transformed_frame, const void* frame_estimate,
+                                                     int64_t nframes, void* stream);
+/* estimate_snr (:189-236): snr_lin[nframes] (the return value), cnrs[nframes][active_subcarriers] (the std::vector argument) */
+int gfdm_hip_channel_estimator_estimate_snr_host(gfdm_hip_channel_estimator* c, float* snr_lin, float* cnrs, const float* rx_preamble, int64_t nframes);
+int gfdm_hip_channel_estimator_estimate_snr_device(gfdm_hip_channel_estimator* c, float* snr_lin, float* cnrs, const void* rx_preamble,
+                                                   int64_t nframes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

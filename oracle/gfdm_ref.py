@@ -254,3 +254,95 @@ def demap_from_resources(grid, M, K, smap, per_timeslot=True, noutput_size=None)
     out = np.swapaxes(act, -1, -2) if per_timeslot else act             # per timeslot: symbol t*A + a
     out = out.reshape(batch + (len(smap) * M,))
     return out if noutput_size is None else out[..., :noutput_size]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Preamble channel estimator: preamble_channel_estimator_cc, lib/preamble_channel_estimator_cc.cc
+
+def gaussian_taps(n_taps=9, sigma_sq=1.0):
+    """initialize_gaussian_filter -- :84-97 (float32 arithmetic in the reference)."""
+    i = np.arange(n_taps, dtype=np.float64) - (n_taps // 2)
+    t = np.exp(-0.5 * i * i / sigma_sq)
+    return t / t.sum()
+
+
+def estimate_preamble_channel(rx_preamble, preamble, fft_len):
+    """estimate_preamble_channel -- :118-145: per half  FFT_K(rx half) * (0.5 / FFT_K(preamble half)), halves summed."""
+    rx = _c128(rx_preamble)
+    p = _c128(preamble)
+    K = fft_len
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv0 = 0.5 / np.fft.fft(p[:K])
+        inv1 = 0.5 / np.fft.fft(p[K:2 * K])
+    return np.fft.fft(rx[..., :K], axis=-1) * inv0 + np.fft.fft(rx[..., K:2 * K], axis=-1) * inv1
+
+
+def filter_preamble_estimate(estimate, fft_len, active, is_dc_free, taps=None):
+    """filter_preamble_estimate -- :147-187: active bins in fftshift order (negative half first), DC bin replaced by the mean
+    of its neighbours when dc-free, edges extended by replication, 9-tap Gaussian smoothing."""
+    e = _c128(estimate)
+    K, A = fft_len, active
+    g = gaussian_taps() if taps is None else np.asarray(taps, dtype=np.float64)
+    nt = len(g)
+    off = 1 if is_dc_free else 0
+    parts = [np.repeat(e[..., K - A // 2:K - A // 2 + 1], nt // 2, axis=-1), e[..., K - A // 2:K]]
+    if is_dc_free:
+        parts.append(((e[..., K - 1] + e[..., 1]) / 2.0)[..., None])
+    parts.append(e[..., off:off + A // 2])
+    parts.append(np.repeat(e[..., off + A // 2 - 1:off + A // 2], nt // 2, axis=-1))
+    inter = np.concatenate(parts, axis=-1)
+    n_out = A + off
+    out = np.zeros(e.shape[:-1] + (n_out,), dtype=np.complex128)
+    for t in range(nt):
+        out += inter[..., t:t + n_out] * g[t]
+    return out
+
+
+def interpolate_frame(filtered, timeslots, fft_len, active, is_dc_free):
+    """interpolate_frame -- :229-262: linear interpolation of the smoothed K-bin estimate to the M*K bins of a block.
+    Without dc-free the reference leaves bins [(A/2 - 1) M, (A/2) M) unwritten; they are filled like the neighbouring
+    constant region here (documented deviation, the tests compare only bins the reference writes)."""
+    est = _c128(filtered)
+    M, K, A = timeslots, fft_len, active
+    n_est = A + (1 if is_dc_free else 0)
+    N = M * K
+    center = N // 2
+    dead = K - A
+    fe = np.zeros(est.shape[:-1] + (N,), dtype=np.complex128)
+    fe[..., M * A // 2 - (0 if is_dc_free else M):center] = est[..., n_est - 1:n_est]
+    fe[..., center:center + M * dead // 2] = est[..., 0:1]
+    j = np.arange(M) / float(M)
+    for i in range(n_est // 2):
+        seg = est[..., i:i + 1] + (est[..., i + 1:i + 2] - est[..., i:i + 1]) * j
+        s0 = center + M * dead // 2 + i * M
+        fe[..., s0:s0 + M] = seg
+    for i in range(n_est // 2, n_est - 1):
+        seg = est[..., i:i + 1] + (est[..., i + 1:i + 2] - est[..., i:i + 1]) * j
+        s0 = (i - n_est // 2) * M
+        fe[..., s0:s0 + M] = seg
+    return fe
+
+
+def estimate_frame(rx_preamble, preamble, timeslots, fft_len, active, is_dc_free):
+    """estimate_frame -- :272-281."""
+    est = estimate_preamble_channel(rx_preamble, preamble, fft_len)
+    return interpolate_frame(filter_preamble_estimate(est, fft_len, active, is_dc_free), timeslots, fft_len, active, is_dc_free)
+
+
+def estimate_snr(rx_preamble, fft_len, active, is_dc_free):
+    """estimate_snr -- :189-227: 2K-point FFT of the two-fold repeated preamble; even bins carry symbol + noise energy, odd bins
+    noise only.  Returns (snr_lin, cnrs[active])."""
+    rx = _c128(rx_preamble)
+    K, A = fft_len, active
+    S = np.abs(np.fft.fft(rx[..., :2 * K], axis=-1)) ** 2
+    half = A // 2
+    off = 1 if is_dc_free else 0
+    pos_hi = 2 * (np.arange(half) + off)
+    pos_lo = 2 * (np.arange(half) + (K - A) // 2 + K // 2)
+    se = np.concatenate((S[..., pos_hi], S[..., pos_lo]), axis=-1)
+    ne = np.concatenate((S[..., pos_hi + 1], S[..., pos_lo + 1]), axis=-1)
+    sym, noise = se.sum(axis=-1), ne.sum(axis=-1)
+    with np.errstate(divide="ignore", invalid="ignore"):     # noise-free input: snr = inf, as in the reference's float division
+        snr = (sym - noise) / noise
+        cnrs = se * np.asarray(snr / (sym / A))[..., None]
+    return snr, cnrs

@@ -26,7 +26,20 @@ def pytest_configure(config):
 def golden_names():
     """kernel-path fixtures (make_golden.py); the composite-transmitter fixtures (make_golden_tx.py) are tx_*"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith("tx_")]
+    return [n for n in names if not n.startswith(("tx_", "est_"))]
+
+
+def est_golden_names():
+    """channel-estimator fixtures (make_golden_est.py)"""
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "est_*.npz")))
+
+
+def load_est_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    for k in ("M", "K", "A"):
+        g[k] = int(g[k])
+    return g
 
 
 def tx_golden_names():

@@ -1,0 +1,170 @@
+"""GPU parity tests of the preamble channel estimator (preamble_channel_estimator_cc).
+Expectations: the reference's Python model of it (tests/golden/est_*.npz, make_golden_est.py), the numpy oracle stage by
+stage, and the properties python/qa_channel_estimator_cc.py checks."""
+import numpy as np
+import pytest
+
+import gfdm_ref as R
+from conftest import assert_places, est_golden_names, have_gpu, load_est_golden, rel_err
+from gfdm_amd.filters import get_frequency_domain_filter
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    if not have_gpu():
+        pytest.fail("no MI355X visible: the HIP path cannot run (there is no CPU fallback to test instead)")
+
+
+def _active_bins(K, A, dc_free):
+    off = 1 if dc_free else 0
+    return np.concatenate((np.arange(off, off + A // 2), np.arange(K - A // 2, K)))
+
+
+@pytest.mark.parametrize("name", est_golden_names())
+def test_estimate_frame_matches_pygfdm(name):
+    import gfdm_amd
+    g = load_est_golden(name)
+    M, K, A = g["M"], g["K"], g["A"]
+    est = gfdm_amd.ChannelEstimator(M, K, A, True, 1, g["preamble"])
+    assert (est.timeslots(), est.fft_len(), est.active_subcarriers(), est.frame_len(), est.is_dc_free()) == (M, K, A, M * K, True)
+    got = est.estimate_frame(g["rx_preambles"])
+    assert got.shape == g["pygfdm_frame_estimates"].shape
+    assert rel_err(got, g["pygfdm_frame_estimates"]) < TOL
+    assert_places(got, g["pygfdm_frame_estimates"], 4)
+    assert np.array_equal(est.estimate_frame(g["rx_preambles"][2]), got[2])       # one preamble == row of the batch
+    # qa_channel_estimator_cc.py:84-85 (clean preamble -> ones, 6 places; float32 here: 5) and :118-125 (channel, 1 place)
+    assert np.max(np.abs(got[0] - 1.0)) < 1e-5
+    fh = np.fft.fft(g["channel"], M * K)
+    act = M * A // 2
+    assert_places(got[1][:act], fh[:act], 1)
+    assert_places(got[1][-act:], fh[-act:], 1)
+    assert np.allclose(est.preamble_filter_taps(), R.gaussian_taps(), atol=1e-7)
+
+
+@pytest.mark.parametrize("M,K,A,dc_free", [(9, 64, 52, True), (9, 64, 52, False), (5, 32, 32, False), (15, 128, 110, True), (7, 12, 8, True),
+                                           (3, 48, 40, False), (2, 1024, 936, True)])
+def test_estimator_stages_against_oracle(M, K, A, dc_free):
+    """every public stage (estimate_preamble_channel, filter_preamble_estimate, interpolate_frame, prepare_for_zf) and their
+    fusion, power-of-two and other fft_len, dc-free or not, random full-band preamble (every bin invertible)."""
+    import gfdm_amd
+    rng = np.random.default_rng(M * K + A + dc_free)
+    B = 6
+    pre = (rng.standard_normal(2 * K) + 1j * rng.standard_normal(2 * K)) / np.sqrt(2)
+    rx = rng.standard_normal((B, 2 * K)) + 1j * rng.standard_normal((B, 2 * K))
+    est = gfdm_amd.ChannelEstimator(M, K, A, dc_free, 0, pre)
+    assert est.filtered_len() == A + dc_free
+    ref_e = R.estimate_preamble_channel(rx, pre, K)
+    ref_f = R.filter_preamble_estimate(ref_e, K, A, dc_free)
+    ref_i = R.interpolate_frame(ref_f, M, K, A, dc_free)
+    got_e = est.estimate_preamble_channel(rx)
+    assert rel_err(got_e, ref_e) < TOL
+    assert rel_err(est.filter_preamble_estimate(ref_e), ref_f) < TOL
+    assert rel_err(est.interpolate_frame(ref_f), ref_i) < TOL
+    fused = est.estimate_frame(rx)
+    assert rel_err(fused, ref_i) < TOL
+    chained = est.interpolate_frame(est.filter_preamble_estimate(got_e))
+    assert rel_err(chained, fused) < 1e-6                                         # same arithmetic up to float32 round trips
+    assert rel_err(est.prepare_for_zf(fused), np.conj(1.0 / fused.astype(np.complex128))) < TOL      # same input: 1/x is ill-conditioned near fades
+    if not dc_free:                                                               # bins the reference itself writes
+        written = np.ones(M * K, bool)
+        written[(A // 2 - 1) * M:(A // 2) * M] = False
+        assert rel_err(fused[:, written], ref_i[:, written]) < TOL
+
+
+def test_estimator_feeds_zero_forcing_receiver_on_device():
+    """preamble -> estimate_frame -> f_eq of the IC receiver, all device resident: transmitted symbols recovered through a
+    frequency-selective channel (the chain of examples/hier_gfdm_receiver.grc)."""
+    import torch
+    import gfdm_amd
+    from gfdm_amd import synth
+    g = load_est_golden("est_cfg2_m9_k64_a52")
+    M, K, A, L = g["M"], g["K"], g["A"], 2
+    N = M * K
+    dev = torch.device("cuda:0")
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    smap = g["smap"]
+    B = 300
+    h = g["channel"]
+    tx = gfdm_amd.Transmitter(M, K, A, 0, 0, 0, smap, True, L, taps, np.zeros(0, complex), [0], [np.zeros(0, complex)])
+    sym = synth.qpsk_symbols(11, B, A * M, dev)
+    blocks = tx.modulate(sym)
+    fh = torch.tensor(np.fft.fft(h, N), dtype=torch.complex64, device=dev)
+    blocks_ch = torch.fft.ifft(torch.fft.fft(blocks, dim=-1) * fh, dim=-1).contiguous()
+    rx_pre = torch.tensor(np.tile(g["rx_preambles"][1], (B, 1)), dtype=torch.complex64, device=dev)
+    est = gfdm_amd.ChannelEstimator(M, K, A, True, 1, g["preamble"])
+    f_eq = est.estimate_frame(rx_pre)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, 4, R.qpsk_points())
+    adv.configure_frames(N, 0, smap, True)
+    rec = adv.demodulate_frames(blocks_ch, f_eq)
+    torch.cuda.synchronize()
+    assert f_eq.shape == (B, N) and rec.shape == sym.shape
+    assert float((rec - sym).abs().max()) < 0.25
+    assert np.array_equal(est.estimate_frame(rx_pre.cpu().numpy()), f_eq.cpu().numpy())      # host path == device path
+
+
+def test_estimate_snr_against_oracle_and_known_level():
+    import torch
+    import gfdm_amd
+    g = load_est_golden("est_cfg2_m9_k64_a52")
+    K, A = g["K"], g["A"]
+    rng = np.random.default_rng(3)
+    clean = g["rx_preambles"][1]
+    B = 256
+    sigma = np.sqrt(np.mean(np.abs(clean) ** 2) / 100.0 / 2)
+    rx = clean[None, :] + sigma * (rng.standard_normal((B, 2 * K)) + 1j * rng.standard_normal((B, 2 * K)))
+    for dc_free in (True, False):
+        est = gfdm_amd.ChannelEstimator(g["M"], K, A, dc_free, 1, g["preamble"] + (0 if dc_free else 0.01))
+        snr, cnrs = est.estimate_snr(rx)
+        ref_snr, ref_cnrs = R.estimate_snr(rx.astype(np.complex64), K, A, dc_free)
+        assert snr.shape == (B,) and cnrs.shape == (B, A)
+        assert np.max(np.abs(snr / ref_snr - 1.0)) < 1e-4
+        assert np.max(np.abs(cnrs - ref_cnrs) / np.max(ref_cnrs)) < 1e-4
+        s1, c1 = est.estimate_snr(rx[5])
+        assert isinstance(s1, float) and s1 == snr[5] and np.array_equal(c1, cnrs[5])
+        d_snr, d_cnrs = est.estimate_snr(torch.tensor(rx, dtype=torch.complex64, device="cuda:0"))
+        torch.cuda.synchronize()
+        assert np.array_equal(d_snr.cpu().numpy(), snr) and np.array_equal(d_cnrs.cpu().numpy(), cnrs)
+    snr, _ = gfdm_amd.ChannelEstimator(g["M"], K, A, True, 1, g["preamble"]).estimate_snr(rx)
+    assert abs(np.mean(snr) / (2 * 100.0 * K / A) - 1.0) < 0.1                   # 20 dB over the band, see test_oracle.py
+
+
+def test_estimator_argument_errors():
+    import gfdm_amd
+    pre = np.ones(128, complex)
+    with pytest.raises(ValueError, match="2 \\* fft_len"):
+        gfdm_amd.ChannelEstimator(9, 64, 52, True, 1, pre[:100])
+    with pytest.raises(ValueError, match="active_subcarriers"):
+        gfdm_amd.ChannelEstimator(9, 64, 64, True, 1, pre)                       # dc-free needs a free bin
+    with pytest.raises(ValueError, match="active_subcarriers"):
+        gfdm_amd.ChannelEstimator(9, 64, 51, True, 1, pre)
+    est = gfdm_amd.ChannelEstimator(9, 64, 52, True, 1, pre)
+    with pytest.raises(RuntimeError, match="multiple"):
+        est.estimate_frame(np.zeros(100, complex))
+
+
+def test_estimator_pybind_surface():
+    """gfdm_python.Preamble_channel_estimator (python/bindings/preamble_channel_estimator_python.cc:30-99) over the C++ class."""
+    import gfdm_python
+    g = load_est_golden("est_ref_m5_k64_a52")
+    M, K, A = g["M"], g["K"], g["A"]
+    est = gfdm_python.Preamble_channel_estimator(M, K, A, True, 1, g["preamble"])
+    assert (est.timeslots(), est.subcarriers(), est.active_subcarriers(), est.frame_len(), est.is_dc_free()) == (M, K, A, M * K, True)
+    one = est.estimate_frame(g["rx_preambles"][1])
+    assert one.shape == (M * K,) and one.dtype == np.complex64
+    assert_places(one, g["pygfdm_frame_estimates"][1], 4)
+    batch = est.estimate_frame(g["rx_preambles"])
+    assert batch.shape == (4, M * K) and np.array_equal(batch[1], one)
+    snr = est.estimate_snr(g["rx_preambles"][3])
+    ref_snr, ref_cnrs = R.estimate_snr(g["rx_preambles"][3].astype(np.complex64), K, A, True)
+    assert isinstance(snr, float) and abs(snr / ref_snr - 1.0) < 1e-4
+    snrs, cnrs = est.estimate_snr_cnrs(g["rx_preambles"])
+    assert snrs.shape == (4,) and cnrs.shape == (4, A) and snrs[3] == np.float32(snr)
+    assert np.max(np.abs(cnrs[3] - ref_cnrs)) / np.max(ref_cnrs) < 1e-4
+    assert np.allclose(est.preamble_filter_taps(), R.gaussian_taps(), atol=1e-7)
+    with pytest.raises(RuntimeError, match="MUST be equal to 2 \\* subcarriers"):
+        est.estimate_frame(np.zeros(100, np.complex64))
+    with pytest.raises(ValueError, match="2 \\* fft_len"):
+        gfdm_python.Preamble_channel_estimator(M, K, A, True, 1, g["preamble"][:100])

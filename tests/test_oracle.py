@@ -164,3 +164,46 @@ def test_transmitter_oracles_match_pygfdm():
             assert rel_err(got, ref) < 1e-7          # pygfdm's mapper rounds the symbols to complex64 (mapping.py:70)
             assert rel_err(co.work(g["symbols"], port), ref) < TOL_F32
             assert_places(co.work(g["symbols"], port), ref, 5)
+
+
+def test_estimator_oracle_matches_pygfdm_and_known_channel():
+    """preamble_channel_estimator_cc restatement against the reference's Python model of it (make_golden_est.py) and against
+    the properties python/qa_channel_estimator_cc.py tests: clean preamble -> all ones (6 places), preamble through a
+    4-tap channel -> fft(h, M*K) on the active bins (1 place)."""
+    from conftest import est_golden_names, load_est_golden
+    assert len(est_golden_names()) >= 4
+    for name in est_golden_names():
+        g = load_est_golden(name)
+        M, K, A = g["M"], g["K"], g["A"]
+        got = R.estimate_frame(g["rx_preambles"], g["preamble"], M, K, A, True)
+        assert np.max(np.abs(got - g["pygfdm_frame_estimates"])) < 1e-12
+        assert np.max(np.abs(got[0] - 1.0)) < 1e-6               # qa_channel_estimator_cc.py:84-85
+        fh = np.fft.fft(g["channel"], M * K)
+        act = M * A // 2                                         # :118-123
+        assert np.max(np.abs(got[1][:act] - fh[:act])) < 0.05 and np.max(np.abs(got[1][-act:] - fh[-act:])) < 0.05
+        # not dc-free: the bins the reference writes agree with the dc-free estimate away from DC (no golden: the Python model
+        # always overwrites DC), the smoothing taps are the normalised Gaussian
+        nd = R.estimate_frame(g["rx_preambles"][1], g["preamble"] + 0.05, M, K, A, False)
+        assert nd.shape == (M * K,) and np.all(np.isfinite(nd))
+    assert abs(R.gaussian_taps().sum() - 1.0) < 1e-15 and np.argmax(R.gaussian_taps()) == 4
+
+
+def test_estimator_snr_properties():
+    """estimate_snr (lib/preamble_channel_estimator_cc.cc:189-227): noise-free two-fold repetition -> odd bins empty;
+    known noise level recovered; cnrs sum to A * snr."""
+    from conftest import load_est_golden
+    g = load_est_golden("est_cfg2_m9_k64_a52")
+    K, A = g["K"], g["A"]
+    rng = np.random.default_rng(0)
+    clean = g["rx_preambles"][1]
+    snrs = []
+    for _ in range(200):
+        sigma = np.sqrt(np.mean(np.abs(clean) ** 2) / 100.0 / 2)                   # 20 dB over the full band
+        snr, cnrs = R.estimate_snr(clean + sigma * (rng.standard_normal(2 * K) + 1j * rng.standard_normal(2 * K)), K, A, True)
+        assert cnrs.shape == (A,) and abs(cnrs.sum() - A * snr) < 1e-9 * A * snr
+        snrs.append(snr)
+    # signal occupies A of K bins: in-band SNR = 100 * K / A; (sym - noise) / noise  => 2x because the even bins collect both halves
+    expect = 2 * 100.0 * K / A
+    assert abs(np.mean(snrs) / expect - 1.0) < 0.1
+    big, _ = R.estimate_snr(clean, K, A, True)
+    assert big > 1e6                                                               # window-free circular preamble: (almost) no odd-bin energy
