@@ -45,6 +45,8 @@ public:
     void estimate_frame_device(void* d_frame_estimates, const void* d_rx_preambles, long nframes, void* hip_stream);
     /* snr_lin[nframes], cnrs[nframes * active_subcarriers] */
     void estimate_snr_batch(float* snr_lin, float* cnrs, const gfdm_complex* rx_preambles, long nframes);
+    /* C-ABI handle, for receiver_kernel_cc / advanced_receiver_kernel_cc::set_channel_estimator */
+    const gfdm_hip_channel_estimator* handle() const { return d_handle; }
 
 private:
     int d_timeslots;

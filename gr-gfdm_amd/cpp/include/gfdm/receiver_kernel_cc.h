@@ -14,6 +14,8 @@ struct gfdm_hip_receiver;
 namespace gr {
 namespace gfdm {
 
+class preamble_channel_estimator_cc;
+
 class GFDM_API receiver_kernel_cc : public gfdm_kernel_utils
 {
 public:
@@ -60,6 +62,15 @@ public:
     void configure_frames(int frame_len, int cp_len, std::vector<int> subcarrier_map, bool per_timeslot);
     void generic_work_frames_batch(gfdm_complex* out, const gfdm_complex* in, const gfdm_complex* f_eq_in, int noutput_size, long nframes);
     void generic_work_frames_device(void* d_out, const void* d_in, const void* d_f_eq, int noutput_size, long nframes, void* hip_stream);
+
+    /* --- additions: the channel estimator fused in front (channel_estimator_cc -> f_eq input in the reference flowgraph, as ONE
+     * kernel).  After set_channel_estimator, generic_work_estimated_* take each block's received core preamble (preamble b at
+     * rx_preambles + b * preamble_stride, 0 = packed) instead of an equaliser vector; the block I/O follows configure_frames when
+     * that was called, else plain blocks (noutput_size ignored).  The estimator object must outlive its use; nullptr detaches. --- */
+    void set_channel_estimator(preamble_channel_estimator_cc* estimator);
+    void generic_work_estimated_batch(gfdm_complex* out, const gfdm_complex* in, const gfdm_complex* rx_preambles, int preamble_stride, int noutput_size, long nblocks);
+    void generic_work_estimated_device(void* d_out, const void* d_in, const void* d_rx_preambles, int preamble_stride, int noutput_size, long nblocks,
+                                       void* hip_stream);
     const char* kernel_name() const;
 
 private:

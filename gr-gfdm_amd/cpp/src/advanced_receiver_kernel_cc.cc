@@ -1,5 +1,6 @@
 // gr::gfdm::advanced_receiver_kernel_cc over the HIP C-ABI (replaces lib/advanced_receiver_kernel_cc.cc of gr-gfdm).
 #include <gfdm/advanced_receiver_kernel_cc.h>
+#include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm_hip.h>
 #include <cmath>
 #include <limits>
@@ -106,6 +107,25 @@ void advanced_receiver_kernel_cc::generic_work_frames_device(void* d_out, const 
 {
     raise(gfdm_hip_advanced_receiver_work_frames_device(d_handle, d_out, d_in, d_f_eq, noutput_size, nframes, hip_stream),
           "advanced receiver generic_work_frames_device");
+}
+
+void advanced_receiver_kernel_cc::set_channel_estimator(preamble_channel_estimator_cc* estimator)
+{
+    raise(gfdm_hip_advanced_receiver_set_channel_estimator(d_handle, estimator ? estimator->handle() : nullptr), "set_channel_estimator");
+}
+
+void advanced_receiver_kernel_cc::generic_work_estimated_batch(gr_complex_t* out, const gr_complex_t* in, const gr_complex_t* rx_preambles,
+                                                               int preamble_stride, int noutput_size, long nblocks)
+{
+    raise(gfdm_hip_advanced_receiver_work_estimated_host(d_handle, fp(out), fp(in), fp(rx_preambles), preamble_stride, noutput_size, nblocks),
+          "advanced receiver generic_work_estimated");
+}
+
+void advanced_receiver_kernel_cc::generic_work_estimated_device(void* d_out, const void* d_in, const void* d_rx_preambles, int preamble_stride,
+                                                                int noutput_size, long nblocks, void* hip_stream)
+{
+    raise(gfdm_hip_advanced_receiver_work_estimated_device(d_handle, d_out, d_in, d_rx_preambles, preamble_stride, noutput_size, nblocks, hip_stream),
+          "advanced receiver generic_work_estimated_device");
 }
 
 const char* advanced_receiver_kernel_cc::kernel_name() const { return gfdm_hip_advanced_receiver_kernel_name(d_handle); }

@@ -1,5 +1,6 @@
 // gr::gfdm::receiver_kernel_cc over the HIP C-ABI (replaces lib/receiver_kernel_cc.cc of gr-gfdm).
 #include <gfdm/receiver_kernel_cc.h>
+#include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm_hip.h>
 #include <algorithm>
 
@@ -114,6 +115,26 @@ void receiver_kernel_cc::generic_work_frames_device(void* d_out, const void* d_i
 {
     throw_on_error(gfdm_hip_receiver_demodulate_frames_device(d_handle, d_out, d_in, d_f_eq, noutput_size, nframes, hip_stream),
                    "receiver generic_work_frames_device");
+}
+
+void receiver_kernel_cc::set_channel_estimator(preamble_channel_estimator_cc* estimator)
+{
+    throw_on_error(gfdm_hip_receiver_set_channel_estimator(d_handle, estimator ? estimator->handle() : nullptr), "set_channel_estimator");
+}
+
+void receiver_kernel_cc::generic_work_estimated_batch(gfdm_complex* out, const gfdm_complex* in, const gfdm_complex* rx_preambles,
+                                                      int preamble_stride, int noutput_size, long nblocks)
+{
+    throw_on_error(gfdm_hip_receiver_demodulate_estimated_host(d_handle, fp(out), fp(in), fp(rx_preambles), preamble_stride, noutput_size, nblocks),
+                   "receiver generic_work_estimated");
+}
+
+void receiver_kernel_cc::generic_work_estimated_device(void* d_out, const void* d_in, const void* d_rx_preambles, int preamble_stride,
+                                                       int noutput_size, long nblocks, void* hip_stream)
+{
+    throw_on_error(gfdm_hip_receiver_demodulate_estimated_device(d_handle, d_out, d_in, d_rx_preambles, preamble_stride, noutput_size, nblocks,
+                                                                 hip_stream),
+                   "receiver generic_work_estimated_device");
 }
 
 const char* receiver_kernel_cc::kernel_name() const { return gfdm_hip_receiver_kernel_name(d_handle); }

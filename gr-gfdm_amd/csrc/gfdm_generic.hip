@@ -15,6 +15,7 @@
 //   IC loop    lib/advanced_receiver_kernel_cc.cc:56-123
 #include "gfdm_plan.h"
 #include "gfdm_tx.h"
+#include "gfdm_est.h"
 
 namespace gfdm {
 namespace {
@@ -95,6 +96,22 @@ __device__ cf* col_fft(cf* a, cf* b, const DevicePlan& p)
     }
     __syncthreads();
     return y;
+}
+
+// estimate_preamble_channel :118-145 -- K-point FFT of both preamble halves, times 0.5 / FFT(known half), summed.
+// a, b: LDS scratch of 2K each; dst: K bins (LDS or global).  Caller syncs afterwards.
+__device__ void estimate_preamble_bins(const EstPlan& e, const cf* __restrict__ rx, cf* a, cf* b, cf* dst)
+{
+    const int K = e.K;
+    for (int i = threadIdx.x; i < 2 * K; i += GT) {
+        const int h = i >= K, q = i - h * K;
+        a[q * 2 + h] = rx[i];                        // [q][half]: both halves go through one column FFT
+    }
+    __syncthreads();
+    DevicePlan p{};
+    p.M = 2; p.K = K; p.log2K = e.log2K; p.wK = e.wK;
+    const cf* E = col_fft<false>(a, b, p);
+    for (int j = threadIdx.x; j < K; j += GT) dst[j] = cfma(E[2 * j], e.inv0[j], cmul(E[2 * j + 1], e.inv1[j]));
 }
 
 __device__ __forceinline__ cf decide(cf x, const IcParams& ic)
@@ -211,8 +228,8 @@ __global__ __launch_bounds__(GT) void k_add_frame(DevicePlan p, TxParams tx, con
     tx_store_preamble(tx, blockIdx.x, threadIdx.x, GT);
 }
 
-__global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams ic, int mode, int s_in_global, cf* __restrict__ out,
-                                                        const cf* __restrict__ in, const cf* __restrict__ f_eq)
+__global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams ic, EstPlan est, int eq_source, int ntiles, int mode, int s_in_global,
+                                                        cf* __restrict__ out, const cf* __restrict__ in, const cf* __restrict__ f_eq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red = reinterpret_cast<float*>(smem);
@@ -223,7 +240,15 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams i
     const cf* x = in + (int64_t)blockIdx.x * (int64_t)(ic.io.in_stride ? ic.io.in_stride : N) + ic.io.in_offset;   // frame -> block
     const bool demap = ic.io.demap && mode != RX_FD;
     cf* o = out + (int64_t)blockIdx.x * (demap ? ic.io.nout : N);
-    const cf* eq = f_eq ? f_eq + (int64_t)blockIdx.x * N : nullptr;
+    const cf* eq = (eq_source == EQ_VECTOR) ? f_eq + (int64_t)blockIdx.x * N : nullptr;
+    cf* filt = t0 + (size_t)ntiles * N + K;                       // EQ_PREAMBLE: smoothed channel estimate, behind the tiles
+    if (eq_source == EQ_PREAMBLE) {                                // channel estimator in front, the tiles are its scratch
+        cf* bins = t0 + (size_t)ntiles * N;
+        estimate_preamble_bins(est, f_eq + (int64_t)blockIdx.x * (est.pre_stride ? est.pre_stride : 2 * K), t0, t1, bins);
+        __syncthreads();
+        for (int i = threadIdx.x; i < est.n_est; i += GT) filt[i] = est_filter_bin(bins, i, est);
+        __syncthreads();
+    }
 
     for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
     __syncthreads();
@@ -244,6 +269,9 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams i
     cf* U = (X == t0) ? t1 : t0;
     if (eq) {                                                      // one-tap equaliser                 :315-316
         for (int idx = threadIdx.x; idx < N; idx += GT) X[idx] = cdiv(X[idx], eq[idx]);
+        __syncthreads();
+    } else if (eq_source == EQ_PREAMBLE) {                         // same, the estimate interpolated on the fly
+        for (int idx = threadIdx.x; idx < N; idx += GT) X[idx] = cdiv(X[idx], est_frame_bin<0>(filt, idx, est));
         __syncthreads();
     }
     // S[k][m] = sum_i taps[((i + L/2) % L) M + m] * X[((k + i + K - L/2) % K) M + m]                    :165-192
@@ -350,18 +378,6 @@ __global__ __launch_bounds__(GT) void k_generic_cancel(DevicePlan p, cf* __restr
 //   prepare_for_zf            :275-281   conj(1 / x)
 // The whole chain stays in LDS: HBM sees the 2K input samples and the M*K output bins once.
 
-__device__ __forceinline__ cf est_filter_src(const cf* est, int u, const EstPlan& e)
-{
-    int v = u - 4;                                   // 4 = taps / 2 replicated edge bins on either side
-    v = v < 0 ? 0 : (v > e.n_est - 1 ? e.n_est - 1 : v);
-    const int half = e.A >> 1;
-    if (v < half) return est[e.K - half + v];
-    if (e.dc_free && v == half) {
-        const cf lo = est[e.K - 1], hi = est[1];
-        return make_float2(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y));
-    }
-    return est[v - half];                            // dc-free: bins 1.., else bins 0..
-}
 
 __global__ __launch_bounds__(GT) void k_estimate(EstPlan e, int in_stage, int out_stage, int zf, cf* __restrict__ out,
                                                  const cf* __restrict__ in)
@@ -374,19 +390,7 @@ __global__ __launch_bounds__(GT) void k_estimate(EstPlan e, int in_stage, int ou
     cf* filt = est + K;
     const int64_t f = blockIdx.x;
     if (in_stage == EST_RX_PREAMBLE) {
-        const cf* rx = in + f * 2 * K;
-        for (int i = threadIdx.x; i < 2 * K; i += GT) {
-            const int h = i >= K, q = i - h * K;
-            a[q * 2 + h] = rx[i];                    // [q][half]: both halves go through one column FFT
-        }
-        __syncthreads();
-        DevicePlan p{};
-        p.M = 2; p.K = K; p.log2K = e.log2K; p.wK = e.wK;
-        const cf* E = col_fft<false>(a, b, p);
-        for (int j = threadIdx.x; j < K; j += GT) {
-            const cf v = cfma(E[2 * j], e.inv0[j], cmul(E[2 * j + 1], e.inv1[j]));
-            if (out_stage == EST_PREAMBLE_CHANNEL) out[f * K + j] = v; else est[j] = v;
-        }
+        estimate_preamble_bins(e, in + f * 2 * K, a, b, out_stage == EST_PREAMBLE_CHANNEL ? out + f * K : est);
         if (out_stage == EST_PREAMBLE_CHANNEL) return;
         __syncthreads();
     } else if (in_stage == EST_PREAMBLE_CHANNEL) {
@@ -395,13 +399,7 @@ __global__ __launch_bounds__(GT) void k_estimate(EstPlan e, int in_stage, int ou
     }
     if (in_stage <= EST_PREAMBLE_CHANNEL) {
         for (int i = threadIdx.x; i < n_est; i += GT) {
-            cf acc = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const cf v = est_filter_src(est, i + t, e);
-                acc.x += v.x * e.gauss[t];
-                acc.y += v.y * e.gauss[t];
-            }
+            const cf acc = est_filter_bin(est, i, e);
             if (out_stage == EST_FILTERED) out[f * n_est + i] = acc; else filt[i] = acc;
         }
         if (out_stage == EST_FILTERED) return;
@@ -410,23 +408,10 @@ __global__ __launch_bounds__(GT) void k_estimate(EstPlan e, int in_stage, int ou
         for (int i = threadIdx.x; i < n_est; i += GT) filt[i] = in[f * n_est + i];
         __syncthreads();
     }
-    const int N = M * K, center = N / 2;
-    const int upper_segments = n_est - 1 - n_est / 2;      // bins [0, M * upper_segments): positive frequencies
-    const int low_start = center + M * (K - e.A) / 2;      // first negative-frequency bin that is interpolated
-    const float step = 1.0f / (float)M;
+    const int N = M * K;
     cf* o = out + f * N;
     for (int n = threadIdx.x; n < N; n += GT) {
-        cf v;
-        int seg = -1, j = 0;
-        if (n < M * upper_segments) { seg = n_est / 2 + n / M; j = n % M; }
-        else if (n < center) v = filt[n_est - 1];
-        else if (n < low_start) v = filt[0];
-        else { seg = (n - low_start) / M; j = (n - low_start) % M; }
-        if (seg >= 0) {
-            const cf lo = filt[seg], hi = filt[seg + 1];
-            const float t = (float)j * step;
-            v = make_float2(lo.x + (hi.x - lo.x) * t, lo.y + (hi.y - lo.y) * t);
-        }
+        cf v = est_frame_bin<0>(filt, n, e);
         if (zf) v = cdiv(make_float2(1.f, 0.f), v), v.y = -v.y;
         o[n] = v;
     }
@@ -515,19 +500,25 @@ hipError_t launch_add_frame(const DevicePlan& p, const TxParams& tx, const cf* i
     return hipGetLastError();
 }
 
-hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq,
+hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const EstPlan* est, int mode, cf* out, const cf* in, const cf* f_eq,
                                   int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
+    const int eq_source = est ? EQ_PREAMBLE : f_eq ? EQ_VECTOR : EQ_NONE;
+    if (est && p.M < 2) return hipErrorInvalidConfiguration;               // the tiles double as the estimator's 2K scratch
+    const size_t extra = est ? (size_t)(2 * p.K + 2) * sizeof(cf) : 0;     // K-bin estimate + smoothed estimate
     int ntiles = 2, s_in_global = 0;
     if (mode == RX_IC && ic.ic_iter > 0) {
-        if (generic_lds_bytes(p.N, 3) <= LDS_MAX) ntiles = 3; else s_in_global = 1;
+        if (generic_lds_bytes(p.N, 3) + extra <= LDS_MAX) ntiles = 3; else s_in_global = 1;
     }
     if (s_in_global && ic.io.demap) return hipErrorInvalidConfiguration;   // the demapped output block is too small to park S in
-    const size_t lds = generic_lds_bytes(p.N, ntiles);
+    const size_t lds = generic_lds_bytes(p.N, ntiles) + extra;
+    if (lds > LDS_MAX) return hipErrorInvalidConfiguration;
     hipError_t e = allow_lds(k_generic_receive, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_generic_receive, dim3((unsigned)nblocks), dim3(GT), lds, s, p, ic, mode, s_in_global, out, in, f_eq);
+    static const EstPlan kNoEst = {};
+    hipLaunchKernelGGL(k_generic_receive, dim3((unsigned)nblocks), dim3(GT), lds, s, p, ic, est ? *est : kNoEst, eq_source, ntiles, mode, s_in_global,
+                       out, in, f_eq);
     return hipGetLastError();
 }
 

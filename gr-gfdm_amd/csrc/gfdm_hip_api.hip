@@ -249,13 +249,14 @@ int run_device(Plan& pl, void* out, const void* in0, int64_t nblocks, Launch lau
     return GFDM_HIP_OK;
 }
 
+// est != nullptr: f_eq points at the received preambles and the kernel derives the equaliser itself (EQ_PREAMBLE)
 hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks,
-                            hipStream_t s)
+                            hipStream_t s, const gfdm::EstPlan* est = nullptr)
 {
-    if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
     const bool plain_io = !ic.io.demap && !ic.io.in_offset && (ic.io.in_stride == 0 || ic.io.in_stride == pl.dp.N);
-    if (pl.family == gfdm::FAMILY_FAST && plain_io) return gfdm::launch_fast_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
-    return gfdm::launch_generic_receive(pl.dp, ic, mode, out, in, f_eq, nblocks, s);
+    if (pl.family == gfdm::FAMILY_FAST && plain_io && !est) return gfdm::launch_fast_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    return gfdm::launch_generic_receive(pl.dp, ic, est, mode, out, in, f_eq, nblocks, s);
 }
 
 hipError_t mod_launch(Plan& pl, const gfdm::TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
@@ -326,10 +327,11 @@ int frame_io_for_call(const FrameIo& f, const Plan& pl, int noutput_size, gfdm::
     return GFDM_HIP_OK;
 }
 
-struct gfdm_hip_receiver { Plan plan; FrameIo frames; };
+struct gfdm_hip_receiver { Plan plan; FrameIo frames; const gfdm_hip_channel_estimator* est = nullptr; };
 struct gfdm_hip_advanced_receiver {
     Plan plan;
     FrameIo frames;
+    const gfdm_hip_channel_estimator* est = nullptr;
     gfdm::IcParams ic{};
     void* d_ic = nullptr;     // points | smap | active
     ~gfdm_hip_advanced_receiver()
@@ -1138,6 +1140,126 @@ int gfdm_hip_channel_estimator_estimate_snr_host(gfdm_hip_channel_estimator* c, 
     HIP_TRY(hipMemcpyAsync(cnrs, d_cnrs, (size_t)nframes * A * sizeof(float), hipMemcpyDeviceToHost, pl.stream));
     HIP_TRY(hipStreamSynchronize(pl.stream));
     return GFDM_HIP_OK;
+}
+
+}  // extern "C"
+
+// ---- receivers that estimate the channel themselves: preamble_channel_estimator_cc fused in front of the receiver kernel ----
+
+namespace {
+
+int est_attach(const Plan& pl, const gfdm_hip_channel_estimator*& slot, const gfdm_hip_channel_estimator* c)
+{
+    if (c && (c->ep.M != pl.dp.M || c->ep.K != pl.dp.K)) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "estimator is for timeslots %d x fft_len %d, the receiver for timeslots %d x subcarriers %d", c->ep.M, c->ep.K,
+                 pl.dp.M, pl.dp.K);
+        return fail(GFDM_HIP_EINVAL, buf);
+    }
+    if (c && c->plan.device != pl.device) return fail(GFDM_HIP_EINVAL, "estimator and receiver live on different devices");
+    slot = c;
+    return GFDM_HIP_OK;
+}
+
+// I/O of one estimated call: the frame configuration if there is one, plain blocks otherwise
+int est_call_io(const FrameIo& f, const Plan& pl, const gfdm_hip_channel_estimator* c, int preamble_stride, int noutput_size, gfdm::RxIo& io,
+                gfdm::EstPlan& ep)
+{
+    if (!c) return fail(GFDM_HIP_EINVAL, "set_channel_estimator has not been called on this handle");
+    if (preamble_stride != 0 && preamble_stride < 2 * pl.dp.K) return fail(GFDM_HIP_EINVAL, "preamble_stride must be 0 (packed) or at least 2 * fft_len");
+    if (f.configured) {
+        int rc = frame_io_for_call(f, pl, noutput_size, io);
+        if (rc != GFDM_HIP_OK) return rc;
+    } else {
+        io.in_stride = pl.dp.N;
+        io.nout = pl.dp.N;
+    }
+    ep = c->ep;
+    ep.pre_stride = preamble_stride ? preamble_stride : 2 * pl.dp.K;
+    return GFDM_HIP_OK;
+}
+
+template <typename DeviceCall>
+int est_call_host(Plan& pl, const gfdm::RxIo& io, const gfdm::EstPlan& ep, float* out, const float* in, const float* rx_preamble, int64_t nblocks,
+                  DeviceCall call)
+{
+    if (nblocks < 0) return fail(GFDM_HIP_EINVAL, "negative block count");
+    if (!rx_preamble) return fail(GFDM_HIP_EINVAL, "NULL buffer");
+    const size_t nb = (size_t)nblocks;
+    const size_t npre = nb ? (nb - 1) * (size_t)ep.pre_stride + 2 * (size_t)ep.K : 0;
+    return run_host_sized(pl, out, nb * io.nout, in, nb * io.in_stride, rx_preamble, npre, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
+        return (hipError_t)(call(o, i, e, (void*)s) == GFDM_HIP_OK ? hipSuccess : hipErrorUnknown);
+    });
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfdm_hip_receiver_set_channel_estimator(gfdm_hip_receiver* r, const gfdm_hip_channel_estimator* c)
+{
+    if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    return est_attach(r->plan, r->est, c);
+}
+
+int gfdm_hip_advanced_receiver_set_channel_estimator(gfdm_hip_advanced_receiver* a, const gfdm_hip_channel_estimator* c)
+{
+    if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    return est_attach(a->plan, a->est, c);
+}
+
+int gfdm_hip_receiver_demodulate_estimated_device(gfdm_hip_receiver* r, void* out, const void* in, const void* rx_preamble, int preamble_stride,
+                                                  int noutput_size, int64_t nblocks, void* stream)
+{
+    if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    if (!rx_preamble) return fail(GFDM_HIP_EINVAL, "NULL buffer");
+    gfdm::IcParams ic = kNoIc;
+    gfdm::EstPlan ep;
+    int rc = est_call_io(r->frames, r->plan, r->est, preamble_stride, noutput_size, ic.io, ep);
+    if (rc != GFDM_HIP_OK) return rc;
+    return run_device(r->plan, out, in, nblocks, [&]() {
+        return rx_launch(r->plan, ic, gfdm::RX_DEMOD, (cf*)out, (const cf*)in, (const cf*)rx_preamble, nblocks, (hipStream_t)stream, &ep);
+    });
+}
+
+int gfdm_hip_advanced_receiver_work_estimated_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* rx_preamble,
+                                                     int preamble_stride, int noutput_size, int64_t nblocks, void* stream)
+{
+    if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    if (!rx_preamble) return fail(GFDM_HIP_EINVAL, "NULL buffer");
+    gfdm::IcParams ic = a->ic;
+    gfdm::EstPlan ep;
+    int rc = est_call_io(a->frames, a->plan, a->est, preamble_stride, noutput_size, ic.io, ep);
+    if (rc != GFDM_HIP_OK) return rc;
+    return run_device(a->plan, out, in, nblocks, [&]() {
+        return rx_launch(a->plan, ic, gfdm::RX_IC, (cf*)out, (const cf*)in, (const cf*)rx_preamble, nblocks, (hipStream_t)stream, &ep);
+    });
+}
+
+int gfdm_hip_receiver_demodulate_estimated_host(gfdm_hip_receiver* r, float* out, const float* in, const float* rx_preamble, int preamble_stride,
+                                                int noutput_size, int64_t nblocks)
+{
+    if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    gfdm::RxIo io{};
+    gfdm::EstPlan ep;
+    int rc = est_call_io(r->frames, r->plan, r->est, preamble_stride, noutput_size, io, ep);
+    if (rc != GFDM_HIP_OK) return rc;
+    return est_call_host(r->plan, io, ep, out, in, rx_preamble, nblocks, [&](cf* o, const cf* i, const cf* e, void* s) {
+        return gfdm_hip_receiver_demodulate_estimated_device(r, o, i, e, preamble_stride, noutput_size, nblocks, s);
+    });
+}
+
+int gfdm_hip_advanced_receiver_work_estimated_host(gfdm_hip_advanced_receiver* a, float* out, const float* in, const float* rx_preamble,
+                                                   int preamble_stride, int noutput_size, int64_t nblocks)
+{
+    if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    gfdm::RxIo io{};
+    gfdm::EstPlan ep;
+    int rc = est_call_io(a->frames, a->plan, a->est, preamble_stride, noutput_size, io, ep);
+    if (rc != GFDM_HIP_OK) return rc;
+    return est_call_host(a->plan, io, ep, out, in, rx_preamble, nblocks, [&](cf* o, const cf* i, const cf* e, void* s) {
+        return gfdm_hip_advanced_receiver_work_estimated_device(a, o, i, e, preamble_stride, noutput_size, nblocks, s);
+    });
 }
 
 }  // extern "C"

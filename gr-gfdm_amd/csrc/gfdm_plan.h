@@ -65,7 +65,8 @@ struct TxParams;   // gfdm_tx.h: resource mapper in front of / cyclic prefix + p
 hipError_t launch_generic_modulate(const DevicePlan& p, const TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
 // transmitter_kernel::add_frame: preamble + cyclic prefix/suffix + ramp of already modulated blocks, port 0 of tx
 hipError_t launch_add_frame(const DevicePlan& p, const TxParams& tx, const cf* in, int64_t nblocks, hipStream_t s);
-hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq,
+struct EstPlan;
+hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const EstPlan* est, int mode, cf* out, const cf* in, const cf* f_eq,
                                   int64_t nblocks, hipStream_t s);
 hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
 hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, const cf* fd, int64_t nblocks, hipStream_t s);
@@ -82,7 +83,7 @@ hipError_t launch_fast_receive(const DevicePlan& p, const IcParams& ic, const cf
 bool rowlane_supports(int M, int K, int L);
 hipError_t launch_rowlane_modulate(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks,
                                    hipStream_t s);
-hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in,
+hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const EstPlan* est, const cf* twT, int mode, cf* out, const cf* in,
                                   const cf* f_eq, int64_t nblocks, hipStream_t s);
 
 // Preamble channel estimator (lib/preamble_channel_estimator_cc.cc): tables of one estimator handle.
@@ -96,6 +97,14 @@ struct EstPlan {
     const cf* wK;         // [K]  exp(-2 pi i j / K)
     const cf* w2K;        // [2K] exp(-2 pi i j / 2K)
     float gauss[9];       // normalised Gaussian smoothing taps (sigma^2 = 1)
+    int pre_stride;       // receivers with EQ_PREAMBLE: samples between the preambles of successive blocks (0 = packed, 2K)
+};
+
+// how a receiver launch gets its one-tap equaliser
+enum EqSource {
+    EQ_NONE = 0,
+    EQ_VECTOR = 1,        // f_eq: N bins per block (generic_work_equalize)
+    EQ_PREAMBLE = 2       // f_eq points at the received preambles; the kernel runs the channel estimator itself
 };
 
 // stages of the estimator chain; a launch runs in_stage -> out_stage inside one kernel

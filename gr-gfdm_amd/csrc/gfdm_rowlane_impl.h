@@ -1,0 +1,623 @@
+// "Row-lane" HIP kernel family for gfx950: one lane per subcarrier row, one GFDM block per K lanes.
+//
+// Why this layout: the benchmark batch (4096 blocks of K = 64, M = 9) is only 2.4 M symbols.  Spread over 256 CUs x 4 SIMDs
+// that is four blocks per SIMD, so a layout that packs several blocks into one wavefront (gfdm_fast.hip: 4 rows per lane)
+// leaves one wavefront per SIMD and the launch runs at the latency of a single wave.  Here a block occupies K lanes (a whole
+// wavefront at K = 64; two at K = 128; four at K = 256): 4096 blocks become 4096 waves = 16 per CU.
+//
+// Decomposition (n = K p + q, f = M j + m):  X[M j + m] = sum_q W_K^{q j} W_N^{q m} (sum_p x[K p + q] W_M^{p m})
+//   phase A  lane q: loads x[K p + q] (a 512-byte contiguous segment per wave instruction), M-point DFT codelet
+//            (gfdm_dft.h), twiddle W_N^{q m} from a [M][K] table (coalesced), row -> the block's single LDS tile
+//   phase B  K-point FFT over q for all M columns: radix-4 Stockham passes IN PLACE in the tile.  Lane (tq, cg) owns the four
+//            rows tq + (K/4) r of column group cg (ceil(M/4) columns): every pass reads exactly those rows, so addresses are
+//            base + immediates.  For K = 64 the rows sit at a Latin-cube slot permutation during the passes (FftLayout) so
+//            that no pass access has an LDS bank conflict; the last pass writes natural order.
+//   phase C  one-tap equaliser X[f] /= f_eq[f] in linear order on the tile (f_eq requested after phase A, coalesced)
+//   phase D  lane k: L-tap filter + fold over rows k - L/2 .. k + L/2 - 1 (+wrap), 1/M folded in, M-point inverse DFT
+//   IC       d_new = d0 - g (*) (dec_{k-1} + dec_{k+1}) with the M-tap circular kernel g = IDFT_M(ic)/M; for K = 64 the
+//            neighbour rows come by DPP wave rotate (no LDS, no ordering point), otherwise through the tile
+//   output   row -> tile, linear read, coalesced store
+// Blocks of K <= 64 lanes live inside one wavefront: their LDS accesses are ordered by the wave's program order, so they
+// are packed four waves to a workgroup and never wait on s_barrier (block_sync).
+// HBM traffic: x (+ f_eq) in, out out; nothing else leaves the CU.  The modulator is the transposed flow; with TXMODE the
+// resource mapper becomes its load stage and cyclic prefix / ramp / preamble its store stage (gfdm_tx.h).
+//
+// Algorithm restated from gr-gfdm: lib/modulator_kernel_cc.cc:98-141, lib/receiver_kernel_cc.cc:165-334,
+// lib/advanced_receiver_kernel_cc.cc:56-123, lib/transmitter_kernel.cc:78-107.
+#pragma once
+#include "gfdm_dft.h"
+#include "gfdm_plan.h"
+#include "gfdm_tx.h"
+#include "gfdm_est.h"
+
+#include <cstdlib>
+
+#ifndef GFDM_ROW_WG
+#define GFDM_ROW_WG 256
+#endif
+
+namespace gfdm {
+namespace {
+
+using namespace dft;
+
+// Diagnostic build only (-DGFDM_STAMPS, scratch/stamps.py): per-wave timestamps of the phase boundaries, written to a
+// side buffer that nothing else reads.  The product library is built without it.
+#ifdef GFDM_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define GFDM_STAMP(slot)                                                                                         \
+    do {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
+        if (g_stamp_buf && (threadIdx.x & 63) == 0)                                                               \
+            g_stamp_buf[((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GFDM_STAMP(slot) do { } while (0)
+#endif
+
+template <int K> struct RowShape {
+    static constexpr int log2K = (K == 4) ? 2 : (K == 8) ? 3 : (K == 16) ? 4 : (K == 32) ? 5 : (K == 64) ? 6 : (K == 128) ? 7 : (K == 256) ? 8 : (K == 512) ? 9 : -1;
+    static_assert(log2K > 0, "row-lane family supports K = 4 .. 512, power of two");
+    static constexpr int NP4 = log2K / 2;
+    static constexpr bool HAS2 = (log2K & 1) != 0;
+    static constexpr int WG = (K >= 128) ? K : GFDM_ROW_WG;   // threads per workgroup (blocks of K <= 64 lanes are packed)
+    static constexpr int BPW = WG / K;                     // blocks per workgroup
+    static constexpr int RG = K / 4;                       // row groups of the FFT passes
+};
+
+constexpr int pow4(int s) { return 1 << (2 * s); }
+
+// Ordering point for the block's LDS tile.  A block of K <= 64 lanes lives inside ONE wavefront, whose LDS instructions
+// execute in program order: only the compiler has to be kept from reordering them (the other waves of the workgroup work
+// on other blocks and are never waited for).  Larger blocks span several waves and need the workgroup barrier.
+template <int K>
+__device__ __forceinline__ void block_sync()
+{
+    if constexpr (K <= 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+// LDS tile: [row][M] complex, rows contiguous (M odd => conflict-free row access); tiles of one block are TS apart
+template <int K, int M> struct RowTile {
+    static constexpr int N = K * M;
+    static constexpr int TS = N + ((RowShape<K>::BPW > 1) ? 16 : 0);
+};
+
+template <int K, int M> constexpr size_t row_lds_bytes() { return (size_t)RowShape<K>::BPW * RowTile<K, M>::TS * sizeof(cf) + 64; }
+
+// EQ_PREAMBLE: per block, behind the tiles, the edge-extended active estimate bins (<= K + 8)
+template <int K> struct EstTile {
+    static constexpr int FS = K + 10;
+    static constexpr size_t bytes = (size_t)RowShape<K>::BPW * FS * sizeof(cf);
+};
+
+// Row placement inside the tile WHILE the subcarrier FFT runs.  In natural order the autosort writes of the first radix-4
+// passes hit rows 4 tq + u resp. j + 16 qq + 4 u, whose b64 slots repeat every 4 lanes (4-way LDS bank conflict).  With the
+// low six row bits read as three radix-4 digits, row = 64 e + 16 b + 4 c + d, a group of 16 neighbouring lanes varies
+//   (c, d) in every pass read and in the row-per-lane write of phase A,   (b, c) in the pass-0 writes,   (b, d) in the pass-1 writes
+// (later passes vary (c, d) again).  The slot  64 e + 16 b + 4 ((c + b) & 3) + ((d + b) & 3)  is a bijection that stays
+// injective mod 16 on each of those digit pairs (and mod 32 on 32 consecutive rows), so none of these accesses has a bank
+// conflict.  The LAST pass writes natural order, which is what the row-per-lane phases (equaliser, filter, IC, output)
+// want.  K < 64 keeps the natural order (correct; several blocks share a wavefront there and the pattern differs).
+template <int K> struct FftLayout {
+    static __device__ __forceinline__ int slot(int row)
+    {
+        if constexpr (K >= 64) {
+            const int b = (row >> 4) & 3, c = (row >> 2) & 3, d = row & 3;
+            return (row & ~63) | (16 * b + 4 * ((c + b) & 3) + ((d + b) & 3));
+        } else {
+            return row;
+        }
+    }
+};
+
+// Radix-4 (and trailing radix-2) Stockham passes over the subcarrier axis, IN PLACE in one LDS tile: every lane first
+// pulls its 4 x CMAX inputs into registers, a barrier separates the reads from the (autosort-permuted) writes.
+// One tile instead of a ping-pong pair halves the LDS footprint, i.e. doubles the resident waves per CU.
+// Input rows are expected at FftLayout<K>::slot(row); the result is in natural row order.
+template <int K, int M, bool INV>
+__device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const cf* __restrict__ wK)
+{
+    using S = RowShape<K>;
+    using LY = FftLayout<K>;
+    constexpr int RG = S::RG, CMAX = (M + 3) / 4;
+    const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+    const cf* rb[4];
+    static_for<0, 4>([&](auto ri) { constexpr int r = decltype(ri)::value; rb[r] = tile + LY::slot(tq + RG * r) * M + c0; });
+    static_for<0, S::NP4>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int str = pow4(s), len = K / str, ms = len / 4;
+        constexpr bool last = (s == S::NP4 - 1) && !S::HAS2;      // the pass that leaves the data in natural order
+        const int j = tq & (str - 1), qq = tq / str;
+        cf w1, w2, w3;
+        if constexpr (ms > 1) {
+            w1 = wK[(qq * str) & (K - 1)];
+            w2 = wK[(qq * 2 * str) & (K - 1)];
+            w3 = wK[(qq * 3 * str) & (K - 1)];
+        }
+        cf* wb[4];
+        static_for<0, 4>([&](auto ui) {
+            constexpr int u = decltype(ui)::value;
+            const int row = j + 4 * str * qq + str * u;
+            wb[u] = tile + (last ? row : LY::slot(row)) * M + c0;
+        });
+        cf x[CMAX][4];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) { x[c][0] = rb[0][c]; x[c][1] = rb[1][c]; x[c][2] = rb[2][c]; x[c][3] = rb[3][c]; }
+        });
+        block_sync<K>();                                          // everyone has its inputs in registers
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                Dft<4, INV>::run(x[c]);
+                if constexpr (ms > 1) {
+                    x[c][1] = cmul_dir<INV>(x[c][1], w1);
+                    x[c][2] = cmul_dir<INV>(x[c][2], w2);
+                    x[c][3] = cmul_dir<INV>(x[c][3], w3);
+                }
+                wb[0][c] = x[c][0]; wb[1][c] = x[c][1]; wb[2][c] = x[c][2]; wb[3][c] = x[c][3];
+            }
+        });
+        block_sync<K>();
+    });
+    if constexpr (S::HAS2) {      // len 2, stride K/2: pairs (tq, tq + K/2), (tq + K/4, tq + 3K/4); reads slots, writes natural rows
+        cf y[CMAX][4];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) { y[c][0] = rb[0][c]; y[c][1] = rb[1][c]; y[c][2] = rb[2][c]; y[c][3] = rb[3][c]; }
+        });
+        block_sync<K>();
+        cf* b = tile + tq * M + c0;
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                b[c] = y[c][0] + y[c][2]; b[2 * RG * M + c] = y[c][0] - y[c][2];
+                b[RG * M + c] = y[c][1] + y[c][3]; b[3 * RG * M + c] = y[c][1] - y[c][3];
+            }
+        });
+        block_sync<K>();
+    }
+}
+
+// lane i <- lane (i -+ 1) mod 64: DPP wave rotates (GFX9 dpp_ctrl 0x13C = wave_ror:1, 0x134 = wave_rol:1)
+__device__ __forceinline__ float dpp_wave_ror1(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_wave_rol1(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x134, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ cf decide_point(cf x, const IcParams& ic)
+{
+    if (ic.decision == 1) {
+        const float s = 0.70710678118654752f;
+        return mk(x.x > 0.f ? s : -s, x.y > 0.f ? s : -s);
+    }
+    int idx = 0;
+    if (ic.decision == 2) {
+        idx = (x.x > 0.f);
+    } else {
+        float best = INFINITY;
+        for (int i = 0; i < ic.npoints; ++i) {
+            const cf pt = ic.points[i];
+            const float dr = x.x - pt.x, di = x.y - pt.y, d = dr * dr + di * di;
+            if (d < best) { best = d; idx = i; }
+        }
+    }
+    return ic.points[idx];
+}
+
+// =====================================================================================================================
+// EQ: EqSource.  EQ_PREAMBLE runs the preamble channel estimator (gfdm_est.h) in front, on the block's own lanes: the two K-point
+// FFTs of the preamble halves reuse the subcarrier FFT on a [K][2] view of the tile, the smoothed estimate (<= K bins) stays in
+// LDS, and phase C interpolates it per bin -- the N-bin equaliser vector never exists in HBM (16 K bytes read instead of 8 N).
+template <int K, int M, int L, int MODE, int EQ, bool ICSYM>
+__global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
+                                                                cf* __restrict__ out, const cf* __restrict__ in,
+                                                                const cf* __restrict__ f_eq, int64_t nblocks)
+{
+    using S = RowShape<K>;
+    constexpr int MS = (EQ == EQ_PREAMBLE) ? M + 2 : M;   // tile row stride: with EQ_PREAMBLE two extra columns carry the preamble halves
+    using T = RowTile<K, MS>;
+    constexpr int N = K * M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int g = threadIdx.x / K, q = threadIdx.x - g * K;            // q doubles as row index k in phase D
+    const int64_t blk = (int64_t)blockIdx.x * S::BPW + g;
+    const bool valid = blk < nblocks;
+    const int64_t base = (valid ? blk : 0) * N;
+    const int64_t in_base = (valid ? blk : 0) * (int64_t)(ic.io.in_stride ? ic.io.in_stride : N) + ic.io.in_offset;   // frame -> block
+    cf* X = reinterpret_cast<cf*>(smem) + g * T::TS;                   // the block's single LDS tile, [row][M]
+
+    GFDM_STAMP(0);
+    // ---- phase A: timeslot DFT of row q, twiddle W_N^{q m}
+    cf v[M];
+    static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = in[in_base + K * pp + q]; });
+    GFDM_STAMP(1);
+    // EQ_PREAMBLE: the received preamble's two halves ride through the subcarrier FFT as columns M and M + 1 of the tile
+    cf pre0, pre1, inv0, inv1;
+    if constexpr (EQ == EQ_PREAMBLE) {
+        const cf* pre = f_eq + (valid ? blk : 0) * (int64_t)(est.pre_stride ? est.pre_stride : 2 * K);
+        pre0 = pre[q];
+        pre1 = pre[K + q];
+        inv0 = est.inv0[q];
+        inv1 = est.inv1[q];
+    }
+    cf tw[M];
+    static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; tw[m] = twT[m * K + q]; });
+    dft_inplace<M, false>(v);
+    {
+        cf* xa = X + FftLayout<K>::slot(q) * MS;                   // row q goes to its FFT slot
+        xa[0] = v[0];
+        static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = cmul(v[m], tw[m]); });
+        if constexpr (EQ == EQ_PREAMBLE) { xa[M] = pre0; xa[M + 1] = pre1; }
+    }
+    block_sync<K>();
+    // The equaliser vector is needed only after the subcarrier FFT: request it now, behind every wave's sample loads
+    // (HBM serves requests roughly in issue order, so the samples of all waves arrive first and the transforms start
+    // earlier; f_eq streams in while phases A/B run).
+    cf heq[EQ == EQ_VECTOR ? M : 1];
+    if constexpr (EQ == EQ_VECTOR) {
+#ifndef GFDM_EAGER_FEQ
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; heq[i] = f_eq[base + q + K * i]; });
+    }
+
+    // ---- phase B: subcarrier FFT, in place
+    lds_subcarrier_fft<K, MS, false>(X, q, p.wK);
+
+    GFDM_STAMP(2);
+    // ---- phase C: X[f] / f_eq[f] in linear order (a conj(b) / |b|^2, reciprocal by v_rcp_f32)              rx:315-316
+    if constexpr (EQ == EQ_VECTOR) {
+        static_for<0, M>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const cf a = X[q + K * i], b = heq[i];
+            const float inv = __builtin_amdgcn_rcpf(b.x * b.x + b.y * b.y);
+            X[q + K * i] = mk((a.x * b.x + a.y * b.y) * inv, (a.y * b.x - a.x * b.y) * inv);
+        });
+        block_sync<K>();
+    } else if constexpr (EQ == EQ_PREAMBLE) {
+        // lane q holds estimate bin q (est:118-145): scatter it to its place in the fftshift-ordered, edge-replicated array the
+        // smoothing filter runs over                                                                       est:147-175
+        cf* inter = reinterpret_cast<cf*>(smem + row_lds_bytes<K, MS>()) + g * EstTile<K>::FS;
+        cf* F = X + M;                                     // smoothed bin i -> column M of row i (dead once its lane has read it)
+        const cf eq = cfma(X[q * MS + M], inv0, cmul(X[q * MS + M + 1], inv1));
+        const int pos = est_active_pos(q, est), n_est = est.n_est;
+        if (pos >= 0) {
+            inter[4 + pos] = eq;
+            if (pos == 0) { inter[0] = eq; inter[1] = eq; inter[2] = eq; inter[3] = eq; }
+            if (pos == n_est - 1) { inter[n_est + 4] = eq; inter[n_est + 5] = eq; inter[n_est + 6] = eq; inter[n_est + 7] = eq; }
+        }
+        block_sync<K>();
+        if (est.dc_free) {                                                         // DC bin: mean of its neighbours
+            if (q == 0) {
+                const cf lo = inter[4 + est.A / 2 - 1], hi = inter[4 + est.A / 2 + 1];
+                inter[4 + est.A / 2] = mk(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y));
+            }
+            block_sync<K>();
+        }
+        if (q < n_est) {                                                           // 9-tap Gaussian         est:176-187
+            cf acc = mk(0.f, 0.f);
+            static_for<0, 9>([&](auto ti) {
+                constexpr int t = decltype(ti)::value;
+                const cf x = inter[q + t];
+                acc.x += x.x * est.gauss[t];
+                acc.y += x.y * est.gauss[t];
+            });
+            F[q * MS] = acc;
+        }
+        block_sync<K>();
+        // row q = bins M q .. M q + M - 1 lies inside one interpolation segment of the smoothed estimate   est:238-273
+        cf lo, hi;
+        est_row_segment(F, MS, q, est, lo, hi);
+        const cf dlt = mk(hi.x - lo.x, hi.y - lo.y);
+        constexpr float step = 1.0f / (float)M;
+        static_for<0, M>([&](auto mi) {
+            constexpr int m = decltype(mi)::value;
+            const float t = (float)m * step;
+            const cf a = X[q * MS + m], b = mk(lo.x + dlt.x * t, lo.y + dlt.y * t);
+            const float inv = __builtin_amdgcn_rcpf(b.x * b.x + b.y * b.y);
+            X[q * MS + m] = mk((a.x * b.x + a.y * b.y) * inv, (a.y * b.x - a.x * b.y) * inv);
+        });
+        block_sync<K>();
+    }
+
+    // ---- phase D: S[k][m] = sum_i taps[((i + L/2) % L) M + m] X[(k + i - L/2) mod K][m]                      rx:165-192
+    cf s[M];
+    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = mk(0.f, 0.f); });
+    static_for<0, L>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const cf* rb = X + ((q + i - L / 2 + K) & (K - 1)) * MS;
+        static_for<0, M>([&](auto mi) {
+            constexpr int m = decltype(mi)::value;
+            s[m] = cfma(p.taps[((i + L / 2) % L) * M + m], rb[m], s[m]);
+        });
+    });
+    constexpr float invM = 1.0f / (float)M;
+    cf d[M];
+    if constexpr (MODE != RX_FD) {
+        // from here on S only feeds inverse DFTs that are scaled by 1/M: fold the scale into S (and into the IC taps)
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = scale(s[m], invM); d[m] = s[m]; });
+        dft_inplace<M, true>(d);                                                                         // rx:211-225
+    }
+    block_sync<K>();                                      // every lane has read its neighbour rows: the tile is free
+    GFDM_STAMP(3);
+
+    if constexpr (MODE == RX_IC) {
+        // One cancellation round of the reference is  d_new = IDFT_M(S - ic (.) DFT_M(nb)) / M  with nb = dec_{k-1} + dec_{k+1}.
+        // Both transforms are linear, so  d_new = d0 - g (*) nb  with d0 = IDFT_M(S)/M (already in d) and the M-tap circular
+        // convolution kernel g = IDFT_M(ic)/M (host table p.icg).  For the usual real, even prototype filters ic is real and
+        // symmetric, hence g is too (ICSYM): M(M+1)/2 packed multiply-adds per row and round instead of two M-point DFTs.
+        const int wgt = ic.active[q];                     // multiplicity of subcarrier k in subcarrier_map (0 = inactive)
+        float* red = reinterpret_cast<float*>(reinterpret_cast<cf*>(smem) + S::BPW * T::TS);
+        cf d0[M];
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d0[m] = d[m]; });
+        for (int it = 0; it < ic.ic_iter; ++it) {                                                        // adv:56-76
+            const bool pc = (ic.do_phase_compensation > 0) && (it == 0);
+            float acc = 0.f;
+            cf dec[M];
+            if (ic.decision == 1 && !pc) {
+                // QPSK hot path (constellation_qpsk::decision_maker: sign tests, zero -> negative point); the per-lane
+                // amplitudes are 0 on inactive subcarriers, so one compare + one select per component           adv:109-123
+                const float sp = (wgt > 0) ? 0.70710678118654752f : 0.f, sn = -sp;
+                static_for<0, M>([&](auto mi) {
+                    constexpr int m = decltype(mi)::value;
+                    dec[m] = mk(d[m].x > 0.f ? sp : sn, d[m].y > 0.f ? sp : sn);
+                });
+            } else {
+                static_for<0, M>([&](auto mi) {                                                          // adv:109-123
+                    constexpr int m = decltype(mi)::value;
+                    dec[m] = (wgt > 0) ? decide_point(d[m], ic) : mk(0.f, 0.f);
+                    if (pc && wgt > 0) acc += (float)wgt * (atan2f(dec[m].y, dec[m].x) - atan2f(d[m].y, d[m].x));
+                });
+            }
+            if (pc) {                                                                                    // adv:59-71, 78-91
+                for (int off = 1; off < 64 && off < K; off <<= 1) acc += __shfl_xor(acc, off, 64);
+                if constexpr (K > 64) {
+                    if ((q & 63) == 0) red[q >> 6] = acc;
+                    block_sync<K>();
+                    acc = 0.f;
+                    static_for<0, K / 64>([&](auto wi) { acc += red[decltype(wi)::value]; });
+                }
+                const float phi = acc / (float)(ic.n_active * M);
+                float sn, cs;
+                sincosf(phi, &sn, &cs);
+                const cf rot = mk(cs, sn);
+                static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d0[m] = cmul(d0[m], rot); });   // rotating S rotates d0
+            }
+            // neighbours k-1 and k+1 (wrap mod K)                                                           rx:274-299
+            cf nb[M];
+            if constexpr (K == 64) {
+                // the block IS the wavefront: subcarrier k +- 1 is lane +- 1 with wrap-around, i.e. a DPP wave rotate --
+                // no LDS traffic and no ordering point in the whole cancellation round
+                static_for<0, M>([&](auto mi) {
+                    constexpr int m = decltype(mi)::value;
+                    nb[m] = mk(dpp_wave_ror1(dec[m].x) + dpp_wave_rol1(dec[m].x), dpp_wave_ror1(dec[m].y) + dpp_wave_rol1(dec[m].y));
+                });
+            } else {
+                static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = dec[m]; });
+                block_sync<K>();
+                const cf* below = X + ((q - 1 + K) & (K - 1)) * M;
+                const cf* above = X + ((q + 1) & (K - 1)) * M;
+                static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; nb[m] = below[m] + above[m]; });
+            }
+            if constexpr (ICSYM) {
+                constexpr int H = (M - 1) / 2;
+                static_for<0, M>([&](auto pi) {
+                    constexpr int pp = decltype(pi)::value;
+                    cf acc = mk(fmaf(-p.icg[0].x, nb[pp].x, d0[pp].x), fmaf(-p.icg[0].x, nb[pp].y, d0[pp].y));
+                    static_for<1, H + 1>([&](auto ri) {
+                        constexpr int r = decltype(ri)::value;
+                        const cf pair = nb[(pp - r + M) % M] + nb[(pp + r) % M];
+                        acc = mk(fmaf(-p.icg[r].x, pair.x, acc.x), fmaf(-p.icg[r].x, pair.y, acc.y));
+                    });
+                    if constexpr (M % 2 == 0) {
+                        const cf mid = nb[(pp + M / 2) % M];
+                        acc = mk(fmaf(-p.icg[M / 2].x, mid.x, acc.x), fmaf(-p.icg[M / 2].x, mid.y, acc.y));
+                    }
+                    d[pp] = acc;
+                });
+            } else {
+                static_for<0, M>([&](auto pi) {
+                    constexpr int pp = decltype(pi)::value;
+                    cf acc = d0[pp];
+                    static_for<0, M>([&](auto ri) {
+                        constexpr int r = decltype(ri)::value;
+                        const cf g = p.icg[r], x = nb[(pp - r + M) % M];
+                        acc = mk(fmaf(-g.x, x.x, fmaf(g.y, x.y, acc.x)), fmaf(-g.x, x.y, fmaf(-g.y, x.x, acc.y)));
+                    });
+                    d[pp] = acc;
+                });
+            }
+            if constexpr (K != 64) block_sync<K>();       // all neighbour reads done before the tile is rewritten
+        }
+    }
+
+    GFDM_STAMP(4);
+    if (MODE != RX_FD && ic.io.demap) {
+        // resource demapper fused into the store: only active subcarriers, in mapper order; for per-timeslot order the lanes of
+        // one timeslot write consecutive output symbols, so no LDS staging is needed                     mapper:91-106,136-163
+        const int a = ic.io.rank[q];
+        if (valid && a >= 0) {
+            cf* o = out + blk * (int64_t)ic.io.nout;
+            static_for<0, M>([&](auto mi) {
+                constexpr int m = decltype(mi)::value;
+                const int idx = ic.io.per_timeslot ? (m * ic.io.A + a) : (a * M + m);
+                if (idx < ic.io.nout) o[idx] = d[m];
+            });
+        }
+    } else {
+        // ---- output: row -> tile, linear read, coalesced store
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = (MODE == RX_FD) ? s[m] : d[m]; });
+        block_sync<K>();
+        if (valid) {
+            static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; out[base + q + K * i] = X[q + K * i]; });
+        }
+    }
+    GFDM_STAMP(5);
+}
+
+// =====================================================================================================================
+// TXMODE 0: plain modulator.  1: input through the resource mapper (transmitter_kernel::modulate).
+// 2: mapper in front AND cyclic prefix / suffix + ramp + preamble behind, all ports (transmitter_kernel::generic_work for every
+// cyclic shift of the reference's transmitter_cc_impl::general_work, lib/transmitter_cc_impl.cc:165-177) -- see gfdm_tx.h.
+template <int K, int M, int L, int TXMODE>
+__global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, TxParams tx, const cf* __restrict__ twT,
+                                                                 cf* __restrict__ out, const cf* __restrict__ in, int64_t nblocks)
+{
+    using S = RowShape<K>;
+    using T = RowTile<K, M>;
+    constexpr int N = K * M;
+    constexpr int PART = (M * L / 2 < M) ? (M * L / 2) : M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int g = threadIdx.x / K, q = threadIdx.x - g * K;
+    const int64_t blk = (int64_t)blockIdx.x * S::BPW + g;
+    const bool valid = blk < nblocks;
+    const int64_t base = (valid ? blk : 0) * N;
+    cf* X = reinterpret_cast<cf*>(smem) + g * T::TS;
+
+    cf v[M];
+    if constexpr (TXMODE == 0) {
+        // symbols [k][p], copied linearly (coalesced) into the tile; lane k then owns row k
+        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; X[q + K * i] = in[base + q + K * i]; });
+        block_sync<K>();
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = X[q * M + m]; });
+    } else {
+        // resource mapper fused into the load: lane k gathers its own subcarrier's symbols (for per-timeslot order the lanes
+        // of one timeslot read consecutive input symbols)
+        const cf* sym = in + (valid ? blk : 0) * (int64_t)tx.nin;
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = tx_symbol(tx, sym, M, q, m); });
+    }
+    dft_inplace<M, false>(v);                                                                          // mod:109-110
+    // gather form of filter + overlap-add: Y[j][m] = sum_i D[(j - i + L/2) mod K][m] taps[((i + L/2) % L) M + m]   mod:116-132
+    constexpr float invN = 1.0f / (float)N;
+    if constexpr (K == 64 && L == 2) {
+        // the block is the wavefront and the only foreign row is j + 1: fetch it with a DPP wave rotate, no LDS round trip
+        static_for<0, M>([&](auto mi) {
+            constexpr int m = decltype(mi)::value;
+            const cf up = mk(dpp_wave_rol1(v[m].x), dpp_wave_rol1(v[m].y));          // D[(j + 1) mod K][m]   (i = 0)
+            cf acc = mk(0.f, 0.f);
+            if constexpr (m < PART) {
+                acc = cfma(up, p.taps[M + m], acc);
+                acc = cfma(v[m], p.taps[m], acc);                                     // D[j][m]              (i = 1)
+            }
+            v[m] = acc;
+        });
+    } else {
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = v[m]; });    // own row: no hazard
+        block_sync<K>();
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = mk(0.f, 0.f); });
+        static_for<0, L>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const cf* rb = X + ((q - i + L / 2 + K) & (K - 1)) * M;
+            static_for<0, PART>([&](auto mi) {
+                constexpr int m = decltype(mi)::value;
+                v[m] = cfma(rb[m], p.taps[((i + L / 2) % L) * M + m], v[m]);
+            });
+        });
+    }
+    block_sync<K>();                                      // neighbour rows read by everyone before they are overwritten
+    {
+        cf* xa = X + FftLayout<K>::slot(q) * M;
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = scale(v[m], invN); });
+    }
+    block_sync<K>();
+    lds_subcarrier_fft<K, M, true>(X, q, p.wK);                                                         // inverse over j
+    v[0] = X[q * M];
+    static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = cmulc(X[q * M + m], twT[m * K + q]); });
+    dft_inplace<M, true>(v);                                                                           // mod:137-140
+    if (valid) {
+        if constexpr (TXMODE == 2) {
+            static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; tx_store_sample(tx, blk, N, K * pp + q, v[pp]); });
+            tx_store_preamble(tx, blk, q, K);
+        } else {
+            static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; out[base + K * pp + q] = v[pp]; });
+        }
+    }
+}
+
+// PART selects which receive kernels a translation unit instantiates (compile time is dominated by the largest shape):
+//   0  frequency-domain output and plain demodulation, equaliser none / vector
+//   1  interference cancellation, equaliser none / vector
+//   2  every mode with the equaliser estimated from the preamble inside the kernel (EQ_PREAMBLE)
+template <int K, int M, int L, int PART>
+hipError_t launch_rx(const DevicePlan& p, const IcParams& ic, const EstPlan* est, const cf* twT, int mode, cf* out, const cf* in, const cf* f_eq,
+                     int64_t nblocks, hipStream_t st)
+{
+    constexpr size_t lds0 = row_lds_bytes<K, (PART == 2 ? M + 2 : M)>();      // EQ_PREAMBLE: two more tile columns
+    static_assert(row_lds_bytes<K, M>() <= 64 * 1024, "row-lane tile exceeds the default dynamic LDS limit");
+    const dim3 grid((unsigned)((nblocks + RowShape<K>::BPW - 1) / RowShape<K>::BPW)), block(RowShape<K>::WG);
+    static const EstPlan kNoEst = {};
+    const EstPlan& e = est ? *est : kNoEst;
+    const size_t lds = lds0 + (PART == 2 ? EstTile<K>::bytes : 0);
+#define GFDM_RX(MODE_, EQ_, SYM_)                                                                                                       \
+    do {                                                                                                                            \
+        if (lds > 64 * 1024) {      /* only the largest shape with the estimate behind its tile */                                 \
+            hipError_t err_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_row_receive<K, M, L, MODE_, EQ_, SYM_>),          \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+            if (err_ != hipSuccess) return err_;                                                                                    \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((k_row_receive<K, M, L, MODE_, EQ_, SYM_>), grid, block, lds, st, p, ic, e, twT, out, in, f_eq, nblocks); \
+    } while (0)
+    const bool ic_rounds = (mode == RX_IC && ic.ic_iter > 0);
+    if constexpr (PART == 2) {
+        if (!est) return hipErrorInvalidValue;
+        if (mode == RX_FD) GFDM_RX(RX_FD, EQ_PREAMBLE, false);
+        else if (!ic_rounds) GFDM_RX(RX_DEMOD, EQ_PREAMBLE, false);
+        else if (p.ic_real_sym) GFDM_RX(RX_IC, EQ_PREAMBLE, true);
+        else GFDM_RX(RX_IC, EQ_PREAMBLE, false);
+    } else if constexpr (PART == 1) {
+        if (est || !ic_rounds) return hipErrorInvalidValue;
+        if (p.ic_real_sym) { if (f_eq) GFDM_RX(RX_IC, EQ_VECTOR, true); else GFDM_RX(RX_IC, EQ_NONE, true); }
+        else { if (f_eq) GFDM_RX(RX_IC, EQ_VECTOR, false); else GFDM_RX(RX_IC, EQ_NONE, false); }
+    } else {
+        if (est || ic_rounds) return hipErrorInvalidValue;
+        if (mode == RX_FD) { if (f_eq) GFDM_RX(RX_FD, EQ_VECTOR, false); else GFDM_RX(RX_FD, EQ_NONE, false); }
+        else { if (f_eq) GFDM_RX(RX_DEMOD, EQ_VECTOR, false); else GFDM_RX(RX_DEMOD, EQ_NONE, false); }
+    }
+#undef GFDM_RX
+    return hipGetLastError();
+}
+
+template <int K, int M, int L>
+hipError_t launch_mod(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t st)
+{
+    constexpr size_t lds = row_lds_bytes<K, M>();
+    const dim3 grid((unsigned)((nblocks + RowShape<K>::BPW - 1) / RowShape<K>::BPW)), block(RowShape<K>::WG);
+    if (tx.mapped && tx.framed) hipLaunchKernelGGL((k_row_modulate<K, M, L, 2>), grid, block, lds, st, p, tx, twT, out, in, nblocks);
+    else if (tx.mapped) hipLaunchKernelGGL((k_row_modulate<K, M, L, 1>), grid, block, lds, st, p, tx, twT, out, in, nblocks);
+    else hipLaunchKernelGGL((k_row_modulate<K, M, L, 0>), grid, block, lds, st, p, tx, twT, out, in, nblocks);
+    return hipGetLastError();
+}
+
+}  // namespace
+}  // namespace gfdm
+
+// gfdm_rowlane_shape.hip is compiled once per (shape, part) -- see the Makefile -- so that the instantiations build in parallel.
+#define GFDM_ROWLANE_RX_PART_I(K_, M_, L_, PART_)                                                                                   \
+    namespace gfdm {                                                                                                                \
+    hipError_t rowlane_rx##PART_##_##K_##_##M_##_##L_(const DevicePlan& p, const IcParams& ic, const EstPlan* est, const cf* twT,  \
+                                                      int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks,             \
+                                                      hipStream_t s)                                                                \
+    {                                                                                                                               \
+        return launch_rx<K_, M_, L_, PART_>(p, ic, est, twT, mode, out, in, f_eq, nblocks, s);                                      \
+    }                                                                                                                               \
+    }
+#define GFDM_ROWLANE_MOD_I(K_, M_, L_)                                                                                              \
+    namespace gfdm {                                                                                                                \
+    hipError_t rowlane_mod_##K_##_##M_##_##L_(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in,        \
+                                              int64_t nblocks, hipStream_t s)                                                       \
+    {                                                                                                                               \
+        return launch_mod<K_, M_, L_>(p, tx, twT, out, in, nblocks, s);                                                             \
+    }                                                                                                                               \
+    }
+// argument macros (-DGFDM_SHAPE_K=..) must be expanded before they are pasted into the function names
+#define GFDM_ROWLANE_RX_PART(K_, M_, L_, PART_) GFDM_ROWLANE_RX_PART_I(K_, M_, L_, PART_)
+#define GFDM_ROWLANE_MOD(K_, M_, L_) GFDM_ROWLANE_MOD_I(K_, M_, L_)

@@ -124,6 +124,12 @@ def lib():
         "gfdm_hip_channel_estimator_prepare_for_zf_device": (i32, [vp, vp, vp, i64, vp]),
         "gfdm_hip_channel_estimator_estimate_snr_host": (i32, [vp, vp, vp, vp, i64]),
         "gfdm_hip_channel_estimator_estimate_snr_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_set_channel_estimator": (i32, [vp, vp]),
+        "gfdm_hip_advanced_receiver_set_channel_estimator": (i32, [vp, vp]),
+        "gfdm_hip_receiver_demodulate_estimated_host": (i32, [vp, vp, vp, vp, i32, i32, i64]),
+        "gfdm_hip_receiver_demodulate_estimated_device": (i32, [vp, vp, vp, vp, i32, i32, i64, vp]),
+        "gfdm_hip_advanced_receiver_work_estimated_host": (i32, [vp, vp, vp, vp, i32, i32, i64]),
+        "gfdm_hip_advanced_receiver_work_estimated_device": (i32, [vp, vp, vp, vp, i32, i32, i64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == the library does not export a declared symbol
@@ -215,6 +221,45 @@ class _Kernel:
         _check(getattr(L, self._frames_prefix + "_host")(self._h, res.ctypes.data, x.ctypes.data, None if e is None else e.ctypes.data, nout_arg, nb))
         return res
 
+    # ---- channel estimator fused in front of the receiver ----
+    def set_channel_estimator(self, estimator):
+        """Attach a ChannelEstimator (or None): demodulate_estimated then derives the equaliser from each block's received preamble."""
+        _check(getattr(lib(), self._set_estimator)(self._h, None if estimator is None else estimator._h))
+        self._estimator = estimator                    # keeps the handle alive
+
+    def demodulate_estimated(self, x, rx_preamble, preamble_stride=0, noutput_size=None, out=None, stream=None):
+        """x: blocks (frames when configure_frames was called); rx_preamble: the received core preamble of every block, preamble b at
+        b * preamble_stride (0 = packed, 2 * subcarriers).  Equals estimate_frame + demodulate_equalize, in one kernel."""
+        L = lib()
+        if getattr(self, "_estimator", None) is None:
+            raise ValueError("set_channel_estimator has not been called on this handle")
+        framed = getattr(self, "_frame_len", None) is not None
+        n_in = self._frame_len if framed else self.block_size()
+        nout_arg = -1 if noutput_size is None else int(noutput_size)
+        nout = (self._frame_nout if noutput_size is None else int(noutput_size)) if framed else self.block_size()
+        stride = int(preamble_stride) if preamble_stride else 2 * self._estimator.fft_len()
+        if _is_tensor(x):
+            import torch
+            nb = x.numel() // n_in
+            out = torch.empty(nb, nout, dtype=torch.complex64, device=x.device) if out is None else out
+            need = (nb - 1) * stride + 2 * self._estimator.fft_len() if nb else 0
+            if not rx_preamble.is_cuda or rx_preamble.dtype != torch.complex64 or not rx_preamble.is_contiguous() or rx_preamble.numel() < need:
+                raise TypeError("rx_preamble must be a contiguous complex64 CUDA/HIP tensor of at least %d elements" % need)
+            _check(getattr(L, self._estimated_prefix + "_device")(self._h, _dev_ptr(out, nb * nout, "out"), _dev_ptr(x, nb * n_in, "in"),
+                                                                 rx_preamble.data_ptr(), int(preamble_stride), nout_arg, nb, _stream_ptr(stream)))
+            return out
+        a = _c64(x)
+        if a.size % n_in:
+            raise RuntimeError("Input size(%d) MUST be a multiple of %d!" % (a.size, n_in))
+        nb = a.size // n_in
+        pre = _c64(rx_preamble)
+        need = (nb - 1) * stride + 2 * self._estimator.fft_len() if nb else 0
+        if pre.size < need:
+            raise RuntimeError("rx_preamble size(%d) MUST be at least %d!" % (pre.size, need))
+        res = np.empty((nb, nout), np.complex64)
+        _check(getattr(L, self._estimated_prefix + "_host")(self._h, res.ctypes.data, a.ctypes.data, pre.ctypes.data, int(preamble_stride), nout_arg, nb))
+        return res
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h and _lib is not None and self._destroy:
@@ -298,6 +343,8 @@ class Demodulator(_Kernel):
     _destroy = "gfdm_hip_receiver_destroy"
     _frames_prefix = "gfdm_hip_receiver_demodulate_frames"
     _configure_frames = "gfdm_hip_receiver_configure_frames"
+    _estimated_prefix = "gfdm_hip_receiver_demodulate_estimated"
+    _set_estimator = "gfdm_hip_receiver_set_channel_estimator"
 
     def __init__(self, timeslots, subcarriers, overlap, taps, device=0):
         L = lib()
@@ -368,6 +415,8 @@ class AdvancedReceiver(_Kernel):
     _destroy = "gfdm_hip_advanced_receiver_destroy"
     _frames_prefix = "gfdm_hip_advanced_receiver_work_frames"
     _configure_frames = "gfdm_hip_advanced_receiver_configure_frames"
+    _estimated_prefix = "gfdm_hip_advanced_receiver_work_estimated"
+    _set_estimator = "gfdm_hip_advanced_receiver_set_channel_estimator"
 
     def __init__(self, timeslots, subcarriers, overlap, taps, subcarrier_map, ic_iter, constellation_points,
                  do_phase_compensation=0, decision="auto", device=0):

@@ -223,6 +223,27 @@ int gfdm_hip_channel_estimator_estimate_snr_host(gfdm_hip_channel_estimator* c, 
 int gfdm_hip_channel_estimator_estimate_snr_device(gfdm_hip_channel_estimator* c, float* snr_lin, float* cnrs, const void* rx_preamble,
                                                    int64_t nframes, void* stream);
 
+/* ---- receivers that estimate the channel themselves (second half) ----
+ * The chain  channel_estimator_cc -> (f_eq input of) simple_receiver_cc / advanced_receiver_sb_cc  of
+ * examples/hier_gfdm_receiver.grc in ONE kernel: the receiver kernel runs estimate_frame on its block's received preamble
+ * and applies the result as its one-tap equaliser; the N-bin estimate never exists in HBM (the preamble's 2 * fft_len samples
+ * are read instead of N equaliser bins).  Results equal estimate_frame followed by generic_work_equalize.
+ * set_channel_estimator: the estimator handle must match (timeslots, subcarriers, device) and outlive its use; NULL detaches.
+ * rx_preamble: preamble of block b at rx_preamble + b * preamble_stride complex (0 = packed, 2 * fft_len) -- a burst buffer
+ *   holding preamble and frame back to back is passed as `in` and, offset to the core preamble, as `rx_preamble`.
+ * The block I/O follows configure_frames when that was called (frames in, demapped symbols out, noutput_size as there),
+ * else plain blocks in and out (noutput_size ignored). */
+int gfdm_hip_receiver_set_channel_estimator(gfdm_hip_receiver* r, const gfdm_hip_channel_estimator* c);
+int gfdm_hip_advanced_receiver_set_channel_estimator(gfdm_hip_advanced_receiver* a, const gfdm_hip_channel_estimator* c);
+int gfdm_hip_receiver_demodulate_estimated_host(gfdm_hip_receiver* r, float* out, const float* in, const float* rx_preamble, int preamble_stride,
+                                                int noutput_size, int64_t nblocks);
+int gfdm_hip_receiver_demodulate_estimated_device(gfdm_hip_receiver* r, void* out, const void* in, const void* rx_preamble, int preamble_stride,
+                                                  int noutput_size, int64_t nblocks, void* stream);
+int gfdm_hip_advanced_receiver_work_estimated_host(gfdm_hip_advanced_receiver* a, float* out, const float* in, const float* rx_preamble,
+                                                   int preamble_stride, int noutput_size, int64_t nblocks);
+int gfdm_hip_advanced_receiver_work_estimated_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* rx_preamble,
+                                                     int preamble_stride, int noutput_size, int64_t nblocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

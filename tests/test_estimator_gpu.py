@@ -168,3 +168,122 @@ def test_estimator_pybind_surface():
         est.estimate_frame(np.zeros(100, np.complex64))
     with pytest.raises(ValueError, match="2 \\* fft_len"):
         gfdm_python.Preamble_channel_estimator(M, K, A, True, 1, g["preamble"][:100])
+
+
+@pytest.mark.parametrize("M,K,L,A,dc_free", [(9, 64, 2, 52, True), (5, 32, 2, 24, True), (9, 32, 2, 28, False), (15, 128, 4, 110, True),
+                                             (31, 256, 2, 220, True), (7, 12, 2, 8, True), (3, 48, 2, 40, False)])
+def test_receivers_with_fused_estimator(M, K, L, A, dc_free):
+    """demodulate_estimated == estimate_frame followed by demodulate_equalize (the oracle's chain), for the plain receiver and the
+    IC receiver, on plain blocks and on bursts (preamble + frame in one buffer, demapped output); row-lane and generic shapes."""
+    import gfdm_amd
+    rng = np.random.default_rng(M * K + A)
+    N, B = M * K, 7
+    taps = get_frequency_domain_filter("rrc", 0.3, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    smap = _active_bins(K, A, dc_free)
+    # known preamble: flat spectrum on every bin (invertible everywhere), two identical halves
+    pre = np.tile(np.fft.ifft(np.exp(2j * np.pi * rng.random(K))) * np.sqrt(K), 2)
+    h = np.array([1, .4 - .2j, .15j, .05])
+    d = np.zeros((B, K, M), complex)
+    d[:, smap, :] = ((1 - 2 * rng.integers(0, 2, (B, A, M))) + 1j * (1 - 2 * rng.integers(0, 2, (B, A, M)))) / np.sqrt(2)
+    gains = np.exp(0.3j * np.arange(B)) * (1 + 0.1 * np.arange(B))             # every burst sees its own channel
+    blocks = np.fft.ifft(np.fft.fft(R.modulate(d.reshape(B, N), nt, M, K, L), axis=-1) * np.fft.fft(h, N), axis=-1) * gains[:, None]
+    rx_pre = np.tile(np.fft.ifft(np.fft.fft(pre[:K]) * np.fft.fft(h, K)), 2)[None, :] * gains[:, None]
+    rx_pre = rx_pre + 1e-3 * (rng.standard_normal((B, 2 * K)) + 1j * rng.standard_normal((B, 2 * K)))
+    feq = R.estimate_frame(rx_pre.astype(np.complex64), pre.astype(np.complex64), M, K, A, dc_free)
+    est = gfdm_amd.ChannelEstimator(M, K, A, dc_free, 1, pre)
+    dem = gfdm_amd.Demodulator(M, K, L, taps)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, 2, R.qpsk_points())
+    with pytest.raises(ValueError, match="set_channel_estimator"):
+        dem.demodulate_estimated(blocks, rx_pre)
+    ref_dem = R.demodulate(blocks, nt, M, K, L, feq)
+    ref_adv = R.advanced_receive(blocks, nt, M, K, L, smap, R.qpsk_points(), 2, f_eq=feq, kind="qpsk")
+    for rx, ref in ((dem, ref_dem), (adv, ref_adv)):
+        rx.set_channel_estimator(est)
+        got = rx.demodulate_estimated(blocks, rx_pre)
+        assert got.shape == (B, N)
+        assert rel_err(got, ref) < 2e-5
+        # the two-kernel chain on the GPU gives the same symbols
+        two_step = rx.demodulate_equalize(blocks.astype(np.complex64), est.estimate_frame(rx_pre))
+        assert rel_err(got, two_step.reshape(B, N)) < 2e-5
+    assert np.max(np.abs(adv.demodulate_estimated(blocks, rx_pre).reshape(B, K, M)[:, smap, :] - d[:, smap, :])) < 0.45    # decisions all correct (coarse estimate at small K)
+    # bursts: [junk | preamble cp | core preamble | cp | block | cs], one buffer for both pointers
+    pcp, cp, cs = K // 4, K // 8 + 1, 3
+    blen = 5 + pcp + 2 * K + cp + N + cs
+    bursts = rng.standard_normal((B, blen)) + 1j * rng.standard_normal((B, blen))
+    bursts[:, 5 + pcp:5 + pcp + 2 * K] = rx_pre
+    off = 5 + pcp + 2 * K + cp
+    bursts[:, off:off + N] = blocks
+    bursts = bursts.astype(np.complex64)
+    for rx, ref in ((dem, ref_dem), (adv, ref_adv)):
+        rx.configure_frames(blen, off, smap[::-1], True)
+        got = rx.demodulate_estimated(bursts, bursts.ravel()[5 + pcp:], preamble_stride=blen)
+        assert got.shape == (B, A * M)
+        assert rel_err(got, R.demap_from_resources(ref, M, K, smap, True)) < 2e-5
+    est2 = gfdm_amd.ChannelEstimator(M + 1, K, A, dc_free, 1, pre)
+    with pytest.raises(ValueError, match="estimator is for"):
+        dem.set_channel_estimator(est2)
+
+
+def test_fused_estimator_device_path_at_batch():
+    import torch
+    import gfdm_amd
+    from gfdm_amd import synth
+    g = load_est_golden("est_cfg2_m9_k64_a52")
+    M, K, A, L = g["M"], g["K"], g["A"], 2
+    N, B = M * K, 4099
+    dev = torch.device("cuda:0")
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    smap = g["smap"]
+    tx = gfdm_amd.Transmitter(M, K, A, 0, 0, 0, smap, True, L, taps, np.zeros(0, complex), [0], [np.zeros(0, complex)])
+    sym = synth.qpsk_symbols(5, B, A * M, dev)
+    fh = torch.tensor(np.fft.fft(g["channel"], N), dtype=torch.complex64, device=dev)
+    blocks = torch.fft.ifft(torch.fft.fft(tx.modulate(sym), dim=-1) * fh, dim=-1).contiguous()
+    rx_pre = torch.tensor(np.tile(g["rx_preambles"][2], (B, 1)), dtype=torch.complex64, device=dev)
+    est = gfdm_amd.ChannelEstimator(M, K, A, True, 1, g["preamble"])
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, 2, R.qpsk_points())
+    assert adv.kernel_name() == "rowlane"
+    adv.configure_frames(N, 0, smap, True)
+    adv.set_channel_estimator(est)
+    fused = adv.demodulate_estimated(blocks, rx_pre)
+    chained = adv.demodulate_frames(blocks, est.estimate_frame(rx_pre))
+    torch.cuda.synchronize()
+    assert fused.shape == sym.shape
+    assert float((fused - chained).abs().max()) < 2e-4
+    assert float((fused - sym).abs().max()) < 0.3
+    assert np.array_equal(adv.demodulate_estimated(blocks[:9].cpu().numpy(), rx_pre[:9].cpu().numpy()), fused[:9].cpu().numpy())
+    adv.set_channel_estimator(None)
+    with pytest.raises(ValueError, match="set_channel_estimator"):
+        adv.demodulate_estimated(blocks, rx_pre)
+
+
+def test_fused_estimator_pybind_surface():
+    """gfdm_python.Demodulator / AdvancedReceiver .set_channel_estimator + .demodulate_estimated (C++ classes over the C-ABI)."""
+    import gfdm_python
+    g = load_est_golden("est_cfg2_m9_k64_a52")
+    M, K, A, L = g["M"], g["K"], g["A"], 2
+    N, B = M * K, 3
+    rng = np.random.default_rng(1)
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L).astype(np.complex64)
+    smap = g["smap"]
+    blocks = (rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N))).astype(np.complex64)
+    rx_pre = g["rx_preambles"][1:4].astype(np.complex64)
+    feq = R.estimate_frame(rx_pre, g["preamble"].astype(np.complex64), M, K, A, True)
+    est = gfdm_python.Preamble_channel_estimator(M, K, A, True, 1, g["preamble"])
+    dem = gfdm_python.Demodulator(M, K, L, taps)
+    dem.set_channel_estimator(est)
+    got = dem.demodulate_estimated(blocks, rx_pre)
+    assert got.shape == (B, N) and got.dtype == np.complex64
+    assert rel_err(got, R.demodulate(blocks, R.normalize_taps(taps, M), M, K, L, feq)) < 2e-5
+    adv = gfdm_python.AdvancedReceiver(M, K, L, taps, smap.tolist(), 2, gfdm_python.Constellation.qpsk(), 0)
+    adv.configure_frames(N, 0, smap.tolist(), True, M)
+    adv.set_channel_estimator(est)
+    got = adv.demodulate_estimated(blocks, rx_pre)
+    ref = R.advanced_receive(blocks, R.normalize_taps(taps, M), M, K, L, smap, R.qpsk_points(), 2, f_eq=feq, kind="qpsk")
+    assert got.shape == (B, A * M)
+    assert rel_err(got, R.demap_from_resources(ref, M, K, smap, True)) < 2e-5
+    with pytest.raises(RuntimeError, match="rx_preamble size"):
+        adv.demodulate_estimated(blocks, rx_pre[:2])
+    adv.set_channel_estimator(None)
+    with pytest.raises(ValueError, match="set_channel_estimator"):
+        adv.demodulate_estimated(blocks, rx_pre)
