@@ -78,39 +78,42 @@ def raw_launcher(fn, handle, out_t, in_ts, nblocks, stream_ptr):
 
 def timed_loop(step_fns, dominant, steps, warmup, world, time_kernel=True):
     """Run warmup + `steps` timed steps.  step_fns[i] is the list of launch closures of ring slot i (each closure is bound
-    to its stream); `dominant` is the index (within a step) of the kernel the roofline describes.  With `time_kernel` a
-    HIP event pair is recorded on the launch stream around every launch of that kernel (single-stream loops only).
-    Returns (wall seconds of the timed region, mean event-bracketed duration in ms of the dominant kernel or None)."""
+    to its stream); `dominant` is the index (within a step) of the kernel the roofline describes.  With `time_kernel`
+    (single-stream loops only) ONE HIP event pair on the launch stream brackets a back-to-back run of the `steps` launches
+    of that kernel, i.e. the launch-to-launch duration: the kernel itself plus the ~1.3 us dispatch gap between two
+    dependent launches (an event pair around every single launch would add another ~2.6 us of event packets to each).
+    Returns (wall seconds of the timed region, mean duration in ms of the dominant kernel or None)."""
     nslots = len(step_fns)
     for i in range(warmup):
         for f in step_fns[i % nslots]:
             f()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if time_kernel else None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if time_kernel:
-        for i in range(steps):
-            fns = step_fns[(warmup + i) % nslots]
-            for j, f in enumerate(fns):
-                if j == dominant:         # HIP events on the launch stream (torch's current stream) around the launch
-                    ev[i][0].record()
-                    f()
-                    ev[i][1].record()
-                else:
-                    f()
-    else:
-        for i in range(steps):
-            for f in step_fns[(warmup + i) % nslots]:
-                f()
+        e0.record()
+    for i in range(steps):
+        for f in step_fns[(warmup + i) % nslots]:
+            f()
+    if time_kernel:
+        e1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kern_ms = float(np.mean([x.elapsed_time(y) for x, y in ev])) if time_kernel else None
+    kern_ms = None
+    if time_kernel:
+        if len(step_fns[0]) > 1:          # several kernels per step: replay only the dominant one over the same ring slots
+            e0.record()
+            for i in range(steps):
+                step_fns[(warmup + i) % nslots][dominant]()
+            e1.record()
+            torch.cuda.synchronize()
+        kern_ms = e0.elapsed_time(e1) / steps
     return wall, kern_ms
 
 
@@ -211,8 +214,8 @@ def main():
     # Steps are independent batches (own ring slot each), so they are pipelined over `--streams` HIP streams: slot s always
     # runs on stream s % S, i.e. within a stream modulate -> demodulate of a slot stay ordered while the load / compute /
     # store phases of neighbouring steps overlap on the GPU.  `value` is timed on that region.  The `roofline` object is
-    # taken from a single-stream replay of the same steps (one kernel on the GPU at a time) with a HIP event pair around
-    # every launch of the dominant kernel, so that its duration is that kernel's own.
+    # taken from a single-stream replay of the same steps (one kernel on the GPU at a time): a HIP event pair around the
+    # back-to-back run of the timed steps' demodulate launches (timed_loop).
     S = max(1, a.streams)
     ns = max(S, (slots(3) // S) * S)
     sym = [synth.qpsk_symbols(gblock(s), B, N, dev) for s in range(ns)]
@@ -252,7 +255,8 @@ def main():
                      "traffic": (18567 + 18432) * 1024 if (B == 4096 and dem.kernel_name() == "rowlane") else None,
                      "kernel": dem.kernel_name() + " (demodulate, MF)", "bytes_per_launch": 16 * N * B,
                      "kernel_ms": kern_ms,
-                     "region": "single-stream replay of the %d timed steps, HIP event pair around every demodulate launch" % a.steps},
+                     "region": "single-stream replay of the %d timed steps' demodulate launches back to back, one HIP event pair around "
+                               "the run (launch-to-launch time: kernel + dispatch gap; rocprofv3 kernel time: profiles/README.md)" % a.steps},
         "kernels": {"modulate": mod.kernel_name(), "demodulate": dem.kernel_name(), "advanced": adv.kernel_name()},
         "output_checksum": [float(v) for v in chk],
     }

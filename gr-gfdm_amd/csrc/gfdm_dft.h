@@ -130,6 +130,28 @@ template <int P, bool INV> struct PrimeDft {
         cf sum = x0;
         static_for<0, H>([&](auto i) { sum = sum + a[decltype(i)::value]; });
         x[0] = sum;
+        if constexpr (P >= 11) {
+            // long accumulations: both components of a complex term share the real factor, i.e. one packed v_pk_fma_f32 per
+            // term (the build disables automatic SLP packing, -fno-slp-vectorize; here the pairing is free of shuffles)
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f av[H], bv[H];
+            static_for<0, H>([&](auto i) { constexpr int n = decltype(i)::value; av[n] = v2f{ a[n].x, a[n].y }; bv[n] = v2f{ b[n].x, b[n].y }; });
+            static_for<0, H>([&](auto ki) {
+                constexpr int k = decltype(ki)::value + 1;
+                v2f re = v2f{ x0.x, x0.y }, im = v2f{ 0.f, 0.f };
+                static_for<0, H>([&](auto ni) {
+                    constexpr int n = decltype(ni)::value + 1;
+                    constexpr float c = (float)cos2pi((long)n * k, P);
+                    constexpr float s = (float)sin2pi((long)n * k, P);
+                    re = __builtin_elementwise_fma(av[n - 1], v2f{ c, c }, re);
+                    im = __builtin_elementwise_fma(bv[n - 1], v2f{ s, s }, im);
+                });
+                const cf lo = mk(re.x + im.y, re.y - im.x), hi = mk(re.x - im.y, re.y + im.x);
+                x[k] = INV ? hi : lo;
+                x[P - k] = INV ? lo : hi;
+            });
+            return;
+        }
         static_for<0, H>([&](auto ki) {
             constexpr int k = decltype(ki)::value + 1;
             cf re = x0, im = mk(0.f, 0.f);

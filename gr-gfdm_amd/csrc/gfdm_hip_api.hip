@@ -242,6 +242,7 @@ int run_device(Plan& pl, void* out, const void* in0, int64_t nblocks, Launch lau
 {
     if (nblocks < 0 || out == nullptr || in0 == nullptr) return fail(GFDM_HIP_EINVAL, "NULL buffer or negative block count");
     if (nblocks == 0) return GFDM_HIP_OK;
+    if (nblocks > 0x7fffffff) return fail(GFDM_HIP_EINVAL, "more than 2^31 - 1 blocks per call (one workgroup or wavefront per block)");
     DeviceGuard guard(pl.device);
     if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
     hipError_t e = launch();

@@ -1,0 +1,488 @@
+"""ctypes binding of the C-ABI in include/gfdm_hip.h (gr-gfdm_amd/lib/libgfdm_hip.so).
+
+Host-side mirror of the reference's kernel-class surface for Python callers that
+work on whole batches and on device-resident torch tensors (bench.py, the
+multi-GPU sharding helper).  The pybind11 module `gfdm_python` is the drop-in for
+the reference's own binding; this module adds nothing numerically, it only
+forwards pointers.  There is no CPU fallback: a missing library or GPU raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.normpath(os.path.join(_PKG, "..", "..", "lib"))
+LIB_PATH = os.environ.get("GFDM_HIP_LIB") or os.path.join(LIB_DIR, "libgfdm_hip.so")   # override: A/B builds of the kernels
+
+OK, EINVAL_TAPS, EINVAL_OVERLAP, EINVAL, ENODEV, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
+DECIDE = {"auto": -1, "nearest": 0, "qpsk": 1, "bpsk": 2}
+
+_lib = None
+
+
+class GfdmHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("gfdm_hip error %d: %s" % (status, message))
+        self.status = status
+
+
+def lib():
+    """Load libgfdm_hip.so (built by `make -C gr-gfdm_amd` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `make -C gr-gfdm_amd` (no CPU fallback exists)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, cp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_char_p
+    sig = {
+        "gfdm_hip_strerror": (cp, [i32]),
+        "gfdm_hip_last_error": (cp, []),
+        "gfdm_hip_device_count": (i32, []),
+        "gfdm_hip_version": (cp, []),
+        "gfdm_hip_modulator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
+        "gfdm_hip_modulator_destroy": (i32, [vp]),
+        "gfdm_hip_modulator_block_size": (i32, [vp]),
+        "gfdm_hip_modulator_filter_taps": (i32, [vp, vp]),
+        "gfdm_hip_modulator_kernel_name": (cp, [vp]),
+        "gfdm_hip_modulator_work_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_modulator_work_device": (i32, [vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
+        "gfdm_hip_receiver_destroy": (i32, [vp]),
+        "gfdm_hip_receiver_block_size": (i32, [vp]),
+        "gfdm_hip_receiver_timeslots": (i32, [vp]),
+        "gfdm_hip_receiver_subcarriers": (i32, [vp]),
+        "gfdm_hip_receiver_overlap": (i32, [vp]),
+        "gfdm_hip_receiver_filter_taps": (i32, [vp, vp]),
+        "gfdm_hip_receiver_ic_filter_taps": (i32, [vp, vp]),
+        "gfdm_hip_receiver_kernel_name": (cp, [vp]),
+        "gfdm_hip_receiver_demodulate_host": (i32, [vp, vp, vp, vp, i64]),
+        "gfdm_hip_receiver_demodulate_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_fft_filter_downsample_host": (i32, [vp, vp, vp, vp, i64]),
+        "gfdm_hip_receiver_fft_filter_downsample_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_transform_subcarriers_to_td_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_receiver_transform_subcarriers_to_td_device": (i32, [vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_cancel_sc_interference_host": (i32, [vp, vp, vp, vp, i64]),
+        "gfdm_hip_receiver_cancel_sc_interference_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_advanced_receiver_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, vp, i32, i32, vp, i32, i32, i32, i32]),
+        "gfdm_hip_advanced_receiver_destroy": (i32, [vp]),
+        "gfdm_hip_advanced_receiver_block_size": (i32, [vp]),
+        "gfdm_hip_advanced_receiver_set_ic": (i32, [vp, i32]),
+        "gfdm_hip_advanced_receiver_get_ic": (i32, [vp]),
+        "gfdm_hip_advanced_receiver_set_phase_compensation": (i32, [vp, i32]),
+        "gfdm_hip_advanced_receiver_get_phase_compensation": (i32, [vp]),
+        "gfdm_hip_advanced_receiver_kernel_name": (cp, [vp]),
+        "gfdm_hip_advanced_receiver_work_host": (i32, [vp, vp, vp, vp, i64]),
+        "gfdm_hip_advanced_receiver_work_device": (i32, [vp, vp, vp, vp, i64, vp]),
+        "gfdm_hip_receiver_configure_frames": (i32, [vp, i32, i32, vp, i32, i32]),
+        "gfdm_hip_receiver_demodulate_frames_host": (i32, [vp, vp, vp, vp, i32, i64]),
+        "gfdm_hip_receiver_demodulate_frames_device": (i32, [vp, vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_advanced_receiver_configure_frames": (i32, [vp, i32, i32, vp, i32, i32]),
+        "gfdm_hip_advanced_receiver_work_frames_host": (i32, [vp, vp, vp, vp, i32, i64]),
+        "gfdm_hip_advanced_receiver_work_frames_device": (i32, [vp, vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_transmitter_create": (i32, [ctypes.POINTER(vp)] + [i32] * 6 + [vp, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32]),
+        "gfdm_hip_transmitter_destroy": (i32, [vp]),
+        "gfdm_hip_transmitter_input_vector_size": (i32, [vp]),
+        "gfdm_hip_transmitter_output_vector_size": (i32, [vp]),
+        "gfdm_hip_transmitter_block_size": (i32, [vp]),
+        "gfdm_hip_transmitter_n_cyclic_shifts": (i32, [vp]),
+        "gfdm_hip_transmitter_cyclic_shift": (i32, [vp, i32]),
+        "gfdm_hip_transmitter_kernel_name": (cp, [vp]),
+        "gfdm_hip_transmitter_work_host": (i32, [vp, vp, i32, vp, i32, i64]),
+        "gfdm_hip_transmitter_work_device": (i32, [vp, vp, i32, vp, i32, i64, vp]),
+        "gfdm_hip_transmitter_modulate_host": (i32, [vp, vp, vp, i32, i64]),
+        "gfdm_hip_transmitter_modulate_device": (i32, [vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_transmitter_add_frame_host": (i32, [vp, vp, vp, i32, i64]),
+        "gfdm_hip_transmitter_add_frame_device": (i32, [vp, vp, vp, i32, i64, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here == the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    L._gfdm_symbols = sorted(sig)
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    return list(lib()._gfdm_symbols)
+
+
+def _check(status):
+    if status == OK:
+        return
+    L = lib()
+    msg = (L.gfdm_hip_last_error() or b"").decode() or L.gfdm_hip_strerror(status).decode()
+    if status in (EINVAL_TAPS, EINVAL_OVERLAP, EINVAL):
+        raise ValueError(msg)            # std::invalid_argument in the reference (pybind11 maps it to ValueError)
+    raise GfdmHipError(status, msg)
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def _is_tensor(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def _dev_ptr(t, n_elems, what):
+    import torch
+    if not t.is_cuda or t.dtype != torch.complex64 or not t.is_contiguous():
+        raise TypeError("%s must be a contiguous complex64 CUDA/HIP tensor" % what)
+    if t.numel() != n_elems:
+        raise RuntimeError("%s has %d elements, expected %d" % (what, t.numel(), n_elems))
+    return t.data_ptr()
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    if hasattr(stream, "cuda_stream"):
+        return stream.cuda_stream
+    return int(stream)
+
+
+class _Kernel:
+    """Shared plumbing: host (numpy) and device (torch) batched calls."""
+    _destroy = None
+    _frames_prefix = None          # C-ABI name stem of the *_frames_* entry points (receivers only)
+    _configure_frames = None
+
+    # ---- raw frames in, demapped symbols out ----
+    def configure_frames(self, frame_len, cp_len, subcarrier_map=None, per_timeslot=True):
+        """Declare the frame layout once: frames of frame_len samples whose block starts cp_len samples in; with a
+        subcarrier_map only the active subcarriers' symbols are emitted, in resource-mapper order."""
+        smap = np.ascontiguousarray([] if subcarrier_map is None else subcarrier_map, dtype=np.int32)
+        fn = getattr(lib(), self._configure_frames)
+        _check(fn(self._h, int(frame_len), int(cp_len), smap.ctypes.data if smap.size else None, smap.size, int(bool(per_timeslot))))
+        self._frame_len = int(frame_len)
+        self._frame_nout = smap.size * (self.block_size() // self._frame_k) if smap.size else self.block_size()
+
+    def demodulate_frames(self, frames, f_eq=None, noutput_size=None, out=None, stream=None):
+        """frames: nframes * frame_len samples; returns (nframes, noutput_size) symbols (all active symbols by default)."""
+        L = lib()
+        nout_arg = -1 if noutput_size is None else int(noutput_size)
+        nout = self._frame_nout if noutput_size is None else int(noutput_size)
+        N = self.block_size()
+        if _is_tensor(frames):
+            import torch
+            nb = frames.numel() // self._frame_len
+            out = torch.empty(nb, nout, dtype=torch.complex64, device=frames.device) if out is None else out
+            feq = None if f_eq is None else _dev_ptr(f_eq, nb * N, "f_eq")
+            _check(getattr(L, self._frames_prefix + "_device")(self._h, _dev_ptr(out, nb * nout, "out"), _dev_ptr(frames, nb * self._frame_len, "frames"),
+                                                              feq, nout_arg, nb, _stream_ptr(stream)))
+            return out
+        x = _c64(frames)
+        if x.size % self._frame_len:
+            raise RuntimeError("frames size(%d) MUST be a multiple of frame_len(%d)!" % (x.size, self._frame_len))
+        nb = x.size // self._frame_len
+        e = None if f_eq is None else _c64(f_eq)
+        if e is not None and e.size != nb * N:
+            raise RuntimeError("Channel vector size(%d) MUST be equal to nframes * block_size(%d)!" % (e.size, nb * N))
+        res = np.empty((nb, nout), np.complex64)
+        _check(getattr(L, self._frames_prefix + "_host")(self._h, res.ctypes.data, x.ctypes.data, None if e is None else e.ctypes.data, nout_arg, nb))
+        return res
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and _lib is not None and self._destroy:
+            getattr(_lib, self._destroy)(h)
+            self._h = None
+
+    def _nblocks(self, size, what="Input"):
+        n = self.block_size()
+        if size % n:
+            raise RuntimeError("%s vector size(%d) MUST be a multiple of block_size(%d)!" % (what, size, n))
+        return size // n
+
+    def _host(self, fn, x, extra=(), extra_ok_none=False):
+        x = _c64(x)
+        nb = self._nblocks(x.size)
+        ptrs = []
+        keep = []
+        for e in extra:
+            if e is None:
+                if not extra_ok_none:
+                    raise RuntimeError("missing input vector")
+                ptrs.append(None)
+            else:
+                e = _c64(e)
+                if e.size != x.size:
+                    raise RuntimeError("Channel vector size(%d) MUST be equal to input size(%d)!" % (e.size, x.size))
+                keep.append(e)
+                ptrs.append(e.ctypes.data)
+        out = np.empty(x.shape, np.complex64)
+        _check(fn(self._h, out.ctypes.data, x.ctypes.data, *ptrs, nb))
+        return out
+
+    def _device(self, fn, out, x, extra=(), stream=None):
+        n = x.numel()
+        nb = self._nblocks(n)
+        ptrs = [None if e is None else _dev_ptr(e, n, "extra input") for e in extra]
+        _check(fn(self._h, _dev_ptr(out, n, "out"), _dev_ptr(x, n, "in"), *ptrs, nb, _stream_ptr(stream)))
+        return out
+
+
+def _taps_arg(taps):
+    t = _c64(np.asarray(taps).ravel())
+    return t, t.ctypes.data, t.size
+
+
+class Modulator(_Kernel):
+    """gr::gfdm::modulator_kernel_cc (include/gfdm/modulator_kernel_cc.h:41-51) on the GPU."""
+    _destroy = "gfdm_hip_modulator_destroy"
+
+    def __init__(self, timeslots, subcarriers, overlap, taps, device=0):
+        L = lib()
+        t, tp, tn = _taps_arg(taps)
+        h = ctypes.c_void_p()
+        _check(L.gfdm_hip_modulator_create(ctypes.byref(h), timeslots, subcarriers, overlap, tp, tn, device))
+        self._h = h
+        self._n = timeslots * subcarriers
+        self._ntaps = tn
+
+    def block_size(self):
+        return self._n
+
+    def kernel_name(self):
+        return lib().gfdm_hip_modulator_kernel_name(self._h).decode()
+
+    def filter_taps(self):
+        out = np.empty(self._ntaps, np.complex64)
+        _check(lib().gfdm_hip_modulator_filter_taps(self._h, out.ctypes.data))
+        return out
+
+    def modulate(self, x, out=None, stream=None):
+        """numpy in -> numpy out (any whole number of blocks); torch CUDA tensor in -> `out` tensor, async on `stream`."""
+        if _is_tensor(x):
+            import torch
+            out = torch.empty_like(x) if out is None else out
+            return self._device(lib().gfdm_hip_modulator_work_device, out, x, stream=stream)
+        return self._host(lib().gfdm_hip_modulator_work_host, x)
+
+
+class Demodulator(_Kernel):
+    """gr::gfdm::receiver_kernel_cc (include/gfdm/receiver_kernel_cc.h:52-89) on the GPU."""
+    _destroy = "gfdm_hip_receiver_destroy"
+    _frames_prefix = "gfdm_hip_receiver_demodulate_frames"
+    _configure_frames = "gfdm_hip_receiver_configure_frames"
+
+    def __init__(self, timeslots, subcarriers, overlap, taps, device=0):
+        L = lib()
+        t, tp, tn = _taps_arg(taps)
+        h = ctypes.c_void_p()
+        _check(L.gfdm_hip_receiver_create(ctypes.byref(h), timeslots, subcarriers, overlap, tp, tn, device))
+        self._h = h
+        self._M, self._K, self._L = timeslots, subcarriers, overlap
+        self._frame_k = subcarriers
+
+    def timeslots(self):
+        return lib().gfdm_hip_receiver_timeslots(self._h)
+
+    def subcarriers(self):
+        return lib().gfdm_hip_receiver_subcarriers(self._h)
+
+    def overlap(self):
+        return lib().gfdm_hip_receiver_overlap(self._h)
+
+    def block_size(self):
+        return self._M * self._K
+
+    def kernel_name(self):
+        return lib().gfdm_hip_receiver_kernel_name(self._h).decode()
+
+    def filter_taps(self):
+        out = np.empty(self._M * self._L, np.complex64)
+        _check(lib().gfdm_hip_receiver_filter_taps(self._h, out.ctypes.data))
+        return out
+
+    def ic_filter_taps(self):
+        out = np.empty(self._M, np.complex64)
+        _check(lib().gfdm_hip_receiver_ic_filter_taps(self._h, out.ctypes.data))
+        return out
+
+    def _call(self, name, x, extra, out, stream, extra_ok_none=False):
+        L = lib()
+        if _is_tensor(x):
+            import torch
+            out = torch.empty_like(x) if out is None else out
+            return self._device(getattr(L, name + "_device"), out, x, extra, stream)
+        return self._host(getattr(L, name + "_host"), x, extra, extra_ok_none)
+
+    def demodulate(self, x, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_demodulate", x, (None,), out, stream, True)
+
+    def demodulate_equalize(self, x, f_eq, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_demodulate", x, (f_eq,), out, stream)
+
+    def fft_filter_downsample(self, x, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_fft_filter_downsample", x, (None,), out, stream, True)
+
+    def fft_equalize_filter_downsample(self, x, f_eq, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_fft_filter_downsample", x, (f_eq,), out, stream)
+
+    def transform_subcarriers_to_td(self, x, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_transform_subcarriers_to_td", x, (), out, stream)
+
+    def cancel_sc_interference(self, td, fd, out=None, stream=None):
+        return self._call("gfdm_hip_receiver_cancel_sc_interference", td, (fd,), out, stream)
+
+
+class AdvancedReceiver(_Kernel):
+    """gr::gfdm::advanced_receiver_kernel_cc (include/gfdm/advanced_receiver_kernel_cc.h:37-78) on the GPU.
+
+    The reference takes a gr::digital::constellation_sptr; here the constellation is its points() array plus a
+    decision rule ('auto' picks the QPSK/BPSK sign tests when the points are those constellations)."""
+    _destroy = "gfdm_hip_advanced_receiver_destroy"
+    _frames_prefix = "gfdm_hip_advanced_receiver_work_frames"
+    _configure_frames = "gfdm_hip_advanced_receiver_configure_frames"
+
+    def __init__(self, timeslots, subcarriers, overlap, taps, subcarrier_map, ic_iter, constellation_points,
+                 do_phase_compensation=0, decision="auto", device=0):
+        L = lib()
+        t, tp, tn = _taps_arg(taps)
+        smap = np.ascontiguousarray(subcarrier_map, dtype=np.int32)
+        pts = _c64(np.asarray(constellation_points).ravel())
+        h = ctypes.c_void_p()
+        _check(L.gfdm_hip_advanced_receiver_create(ctypes.byref(h), timeslots, subcarriers, overlap, tp, tn,
+                                                   smap.ctypes.data, smap.size, ic_iter, pts.ctypes.data, pts.size,
+                                                   DECIDE[decision], do_phase_compensation, device))
+        self._h = h
+        self._n = timeslots * subcarriers
+        self._frame_k = subcarriers
+
+    def block_size(self):
+        return self._n
+
+    def kernel_name(self):
+        return lib().gfdm_hip_advanced_receiver_kernel_name(self._h).decode()
+
+    def set_ic(self, ic_iter):
+        _check(lib().gfdm_hip_advanced_receiver_set_ic(self._h, ic_iter))
+
+    def get_ic(self):
+        return lib().gfdm_hip_advanced_receiver_get_ic(self._h)
+
+    def set_phase_compensation(self, enable):
+        _check(lib().gfdm_hip_advanced_receiver_set_phase_compensation(self._h, enable))
+
+    def get_phase_compensation(self):
+        return lib().gfdm_hip_advanced_receiver_get_phase_compensation(self._h)
+
+    def _call(self, x, f_eq, out, stream):
+        L = lib()
+        if _is_tensor(x):
+            import torch
+            out = torch.empty_like(x) if out is None else out
+            return self._device(L.gfdm_hip_advanced_receiver_work_device, out, x, (f_eq,), stream)
+        return self._host(L.gfdm_hip_advanced_receiver_work_host, x, (f_eq,), True)
+
+    def demodulate(self, x, out=None, stream=None):
+        """generic_work: IC receiver without equaliser."""
+        return self._call(x, None, out, stream)
+
+    def demodulate_equalize(self, x, f_eq, out=None, stream=None):
+        """generic_work_equalize: one f_eq vector per block."""
+        return self._call(x, f_eq, out, stream)
+
+
+class Transmitter(_Kernel):
+    """gr::gfdm::transmitter_kernel (include/gfdm/transmitter_kernel.h:43-85) on the GPU: resource mapper -> modulator ->
+    cyclic prefix/suffix with cyclic shift + window ramp -> preamble as ONE kernel, every cyclic shift ("port") at once."""
+    _destroy = "gfdm_hip_transmitter_destroy"
+
+    def __init__(self, timeslots, subcarriers, active_subcarriers, cp_len, cs_len, ramp_len, subcarrier_map, per_timeslot, overlap,
+                 frequency_taps, window_taps, cyclic_shifts, preambles, device=0):
+        L = lib()
+        t, tp, tn = _taps_arg(frequency_taps)
+        w = _c64(np.asarray(window_taps).ravel())
+        smap = np.ascontiguousarray(subcarrier_map, dtype=np.int32)
+        shifts = np.ascontiguousarray(cyclic_shifts, dtype=np.int32)
+        pre = [np.asarray(p).ravel() for p in preambles]
+        if len(pre) != shifts.size:
+            raise ValueError("Number of cyclic shifts and number of preambles do not match!")
+        if any(p.size != pre[0].size for p in pre):
+            raise ValueError("All preambles must have equal size!")
+        pre = _c64(np.stack(pre)) if pre else np.zeros((0, 0), np.complex64)
+        h = ctypes.c_void_p()
+        _check(L.gfdm_hip_transmitter_create(ctypes.byref(h), timeslots, subcarriers, active_subcarriers, cp_len, cs_len, ramp_len,
+                                             smap.ctypes.data, smap.size, int(bool(per_timeslot)), overlap, tp, tn, w.ctypes.data, w.size,
+                                             shifts.ctypes.data, shifts.size, pre.ctypes.data, pre.shape[1] if pre.size else 0, device))
+        self._h = h
+        self._shifts = [int(x) for x in shifts]
+
+    def input_vector_size(self):
+        return lib().gfdm_hip_transmitter_input_vector_size(self._h)
+
+    def output_vector_size(self):
+        return lib().gfdm_hip_transmitter_output_vector_size(self._h)
+
+    def block_size(self):
+        return lib().gfdm_hip_transmitter_block_size(self._h)
+
+    def cyclic_shifts(self):
+        return list(self._shifts)
+
+    def kernel_name(self):
+        return lib().gfdm_hip_transmitter_kernel_name(self._h).decode()
+
+    def _split(self, x, ninput_size):
+        n = self.input_vector_size() if ninput_size is None else int(ninput_size)
+        size = x.numel() if _is_tensor(x) else np.asarray(x).size
+        if n <= 0 or size % n:
+            raise RuntimeError("input size(%d) MUST be a multiple of ninput_size(%d)!" % (size, n))
+        return n, size // n
+
+    def transmit(self, symbols, ninput_size=None, n_ports=None, stream=None):
+        """All ports (or the first n_ports): list of (nblocks, output_vector_size) arrays / tensors, one per cyclic shift."""
+        L = lib()
+        n, nb = self._split(symbols, ninput_size)
+        ports = len(self._shifts) if n_ports is None else n_ports
+        F = self.output_vector_size()
+        if _is_tensor(symbols):
+            import torch
+            outs = [torch.empty(nb, F, dtype=torch.complex64, device=symbols.device) for _ in range(ports)]
+            arr = (ctypes.c_void_p * ports)(*[o.data_ptr() for o in outs])
+            _check(L.gfdm_hip_transmitter_work_device(self._h, arr, ports, _dev_ptr(symbols, nb * n, "in"), n, nb, _stream_ptr(stream)))
+            return outs
+        x = _c64(symbols)
+        outs = [np.empty((nb, F), np.complex64) for _ in range(ports)]
+        arr = (ctypes.c_void_p * ports)(*[o.ctypes.data for o in outs])
+        _check(L.gfdm_hip_transmitter_work_host(self._h, arr, ports, x.ctypes.data, n, nb))
+        return outs
+
+    def generic_work(self, symbols, ninput_size=None):
+        """transmitter_kernel::generic_work: the frame of cyclic_shifts[0]."""
+        return self.transmit(symbols, ninput_size, 1)[0]
+
+    def modulate(self, symbols, ninput_size=None, stream=None):
+        L = lib()
+        n, nb = self._split(symbols, ninput_size)
+        N = self.block_size()
+        if _is_tensor(symbols):
+            import torch
+            out = torch.empty(nb, N, dtype=torch.complex64, device=symbols.device)
+            _check(L.gfdm_hip_transmitter_modulate_device(self._h, out.data_ptr(), _dev_ptr(symbols, nb * n, "in"), n, nb, _stream_ptr(stream)))
+            return out
+        x = _c64(symbols)
+        out = np.empty((nb, N), np.complex64)
+        _check(L.gfdm_hip_transmitter_modulate_host(self._h, out.ctypes.data, x.ctypes.data, n, nb))
+        return out
+
+    def add_frame(self, blocks, cyclic_shift, stream=None):
+        L = lib()
+        N, F = self.block_size(), self.output_vector_size()
+        if _is_tensor(blocks):
+            import torch
+            nb = blocks.numel() // N
+            out = torch.empty(nb, F, dtype=torch.complex64, device=blocks.device)
+            _check(L.gfdm_hip_transmitter_add_frame_device(self._h, out.data_ptr(), _dev_ptr(blocks, nb * N, "in"), int(cyclic_shift), nb, _stream_ptr(stream)))
+            return out
+        x = _c64(blocks)
+        nb = x.size // N
+        out = np.empty((nb, F), np.complex64)
+        _check(L.gfdm_hip_transmitter_add_frame_host(self._h, out.ctypes.data, x.ctypes.data, int(cyclic_shift), nb))
+        return out

@@ -1,7 +1,7 @@
 """Launch one receiver/modulator variant repeatedly (for rocprofv3 --pmc / --kernel-trace runs)."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "gr-gfdm_amd", "python"))
+sys.path.insert(0, os.environ.get("GFDM_PKG") or os.path.join(ROOT, "gr-gfdm_amd", "python"))   # GFDM_PKG: A/B against an older package + library
 import numpy as np, torch
 import gfdm_amd
 from gfdm_amd import synth
