@@ -379,7 +379,7 @@ __global__ __launch_bounds__(GT) void k_generic_cancel(DevicePlan p, cf* __restr
 // The whole chain stays in LDS: HBM sees the 2K input samples and the M*K output bins once.
 
 
-__global__ __launch_bounds__(GT) void k_estimate(EstPlan e, int in_stage, int out_stage, int zf, cf* __restrict__ out,
+__global__ __launch_bounds__(GT) void k_estimate(EstPlan e, int in_stage, int out_stage, cf* __restrict__ out,
                                                  const cf* __restrict__ in)
 {
     extern __shared__ cf lds[];
@@ -411,9 +411,7 @@ __global__ __launch_bounds__(GT) void k_estimate(EstPlan e, int in_stage, int ou
     const int N = M * K;
     cf* o = out + f * N;
     for (int n = threadIdx.x; n < N; n += GT) {
-        cf v = est_frame_bin<0>(filt, n, e);
-        if (zf) v = cdiv(make_float2(1.f, 0.f), v), v.y = -v.y;
-        o[n] = v;
+        o[n] = est_frame_bin<0>(filt, n, e);
     }
 }
 
@@ -546,13 +544,13 @@ size_t estimator_lds_bytes(int K) { return (size_t)(6 * K + 1) * sizeof(cf); }  
 
 bool estimator_supports(int K) { return estimator_lds_bytes(K) <= LDS_MAX; }
 
-hipError_t launch_estimate(const EstPlan& e, int in_stage, int out_stage, int zf, cf* out, const cf* in, int64_t nframes, hipStream_t s)
+hipError_t launch_estimate(const EstPlan& e, int in_stage, int out_stage, cf* out, const cf* in, int64_t nframes, hipStream_t s)
 {
     if (nframes <= 0) return hipSuccess;
     const size_t lds = estimator_lds_bytes(e.K);
     hipError_t err = allow_lds(k_estimate, lds);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(k_estimate, dim3((unsigned)nframes), dim3(GT), lds, s, e, in_stage, out_stage, zf, out, in);
+    hipLaunchKernelGGL(k_estimate, dim3((unsigned)nframes), dim3(GT), lds, s, e, in_stage, out_stage, out, in);
     return hipGetLastError();
 }
 

@@ -953,22 +953,26 @@ int est_stage_elems(const gfdm::EstPlan& e, int stage)
     }
 }
 
-int est_run_device(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, int zf, void* out, const void* in, int64_t nframes, void* stream)
+int est_run_device(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, void* out, const void* in, int64_t nframes, void* stream)
 {
     if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
     return run_device(c->plan, out, in, nframes, [&]() {
-        return gfdm::launch_estimate(c->ep, in_stage, out_stage, zf, static_cast<cf*>(out), static_cast<const cf*>(in), nframes,
+        if (c->plan.family == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
+            return gfdm::launch_rowlane_estimate(c->ep, static_cast<cf*>(out), static_cast<const cf*>(in), nframes, static_cast<hipStream_t>(stream));
+        return gfdm::launch_estimate(c->ep, in_stage, out_stage, static_cast<cf*>(out), static_cast<const cf*>(in), nframes,
                                      static_cast<hipStream_t>(stream));
     });
 }
 
-int est_run_host(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, int zf, float* out, const float* in, int64_t nframes)
+int est_run_host(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, float* out, const float* in, int64_t nframes)
 {
     if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
     if (nframes < 0) return fail(GFDM_HIP_EINVAL, "negative frame count");
     const size_t nout = (size_t)nframes * est_stage_elems(c->ep, out_stage), nin = (size_t)nframes * est_stage_elems(c->ep, in_stage);
     return run_host_sized(c->plan, out, nout, in, nin, nullptr, 0, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
-        return gfdm::launch_estimate(c->ep, in_stage, out_stage, zf, o, i, nframes, s);
+        if (c->plan.family == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
+            return gfdm::launch_rowlane_estimate(c->ep, o, i, nframes, s);
+        return gfdm::launch_estimate(c->ep, in_stage, out_stage, o, i, nframes, s);
     });
 }
 
@@ -1023,7 +1027,11 @@ int gfdm_hip_channel_estimator_create(gfdm_hip_channel_estimator** out, int time
     e.inv1 = e.inv0 + K;
     e.wK = e.inv1 + K;
     e.w2K = e.wK + K;
-    c->plan.kernel_name = "generic_lds";
+    // estimate_frame runs in the row-lane layout where a shape with this (fft_len, timeslots) is instantiated; the single stages,
+    // prepare_for_zf and estimate_snr always use the generic kernels.  GFDM_HIP_FAMILY=generic forces the generic estimate_frame.
+    const char* want = getenv("GFDM_HIP_FAMILY");
+    c->plan.family = (gfdm::rowlane_supports_estimate(timeslots, K) && !(want && !strcmp(want, "generic"))) ? gfdm::FAMILY_ROWLANE : gfdm::FAMILY_GENERIC;
+    c->plan.kernel_name = c->plan.family == gfdm::FAMILY_ROWLANE ? "rowlane" : "generic_lds";
     *out = c.release();
     return GFDM_HIP_OK;
 }
@@ -1035,6 +1043,7 @@ int gfdm_hip_channel_estimator_active_subcarriers(const gfdm_hip_channel_estimat
 int gfdm_hip_channel_estimator_frame_len(const gfdm_hip_channel_estimator* c) { return c ? c->ep.M * c->ep.K : GFDM_HIP_EINVAL; }
 int gfdm_hip_channel_estimator_is_dc_free(const gfdm_hip_channel_estimator* c) { return c ? c->ep.dc_free : GFDM_HIP_EINVAL; }
 int gfdm_hip_channel_estimator_filtered_len(const gfdm_hip_channel_estimator* c) { return c ? c->ep.n_est : GFDM_HIP_EINVAL; }
+const char* gfdm_hip_channel_estimator_kernel_name(const gfdm_hip_channel_estimator* c) { return c ? c->plan.kernel_name.c_str() : ""; }
 
 int gfdm_hip_channel_estimator_preamble_filter_taps(const gfdm_hip_channel_estimator* c, float* out)
 {
@@ -1046,46 +1055,46 @@ int gfdm_hip_channel_estimator_preamble_filter_taps(const gfdm_hip_channel_estim
 int gfdm_hip_channel_estimator_estimate_frame_device(gfdm_hip_channel_estimator* c, void* frame_estimate, const void* rx_preamble,
                                                      int64_t nframes, void* stream)
 {
-    return est_run_device(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_FRAME, 0, frame_estimate, rx_preamble, nframes, stream);
+    return est_run_device(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_FRAME, frame_estimate, rx_preamble, nframes, stream);
 }
 
 int gfdm_hip_channel_estimator_estimate_frame_host(gfdm_hip_channel_estimator* c, float* frame_estimate, const float* rx_preamble, int64_t nframes)
 {
-    return est_run_host(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_FRAME, 0, frame_estimate, rx_preamble, nframes);
+    return est_run_host(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_FRAME, frame_estimate, rx_preamble, nframes);
 }
 
 int gfdm_hip_channel_estimator_estimate_preamble_channel_device(gfdm_hip_channel_estimator* c, void* fd_preamble_channel, const void* rx_preamble,
                                                                 int64_t nframes, void* stream)
 {
-    return est_run_device(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_PREAMBLE_CHANNEL, 0, fd_preamble_channel, rx_preamble, nframes, stream);
+    return est_run_device(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_PREAMBLE_CHANNEL, fd_preamble_channel, rx_preamble, nframes, stream);
 }
 
 int gfdm_hip_channel_estimator_estimate_preamble_channel_host(gfdm_hip_channel_estimator* c, float* fd_preamble_channel, const float* rx_preamble,
                                                               int64_t nframes)
 {
-    return est_run_host(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_PREAMBLE_CHANNEL, 0, fd_preamble_channel, rx_preamble, nframes);
+    return est_run_host(c, gfdm::EST_RX_PREAMBLE, gfdm::EST_PREAMBLE_CHANNEL, fd_preamble_channel, rx_preamble, nframes);
 }
 
 int gfdm_hip_channel_estimator_filter_preamble_estimate_device(gfdm_hip_channel_estimator* c, void* filtered, const void* estimate, int64_t nframes,
                                                                void* stream)
 {
-    return est_run_device(c, gfdm::EST_PREAMBLE_CHANNEL, gfdm::EST_FILTERED, 0, filtered, estimate, nframes, stream);
+    return est_run_device(c, gfdm::EST_PREAMBLE_CHANNEL, gfdm::EST_FILTERED, filtered, estimate, nframes, stream);
 }
 
 int gfdm_hip_channel_estimator_filter_preamble_estimate_host(gfdm_hip_channel_estimator* c, float* filtered, const float* estimate, int64_t nframes)
 {
-    return est_run_host(c, gfdm::EST_PREAMBLE_CHANNEL, gfdm::EST_FILTERED, 0, filtered, estimate, nframes);
+    return est_run_host(c, gfdm::EST_PREAMBLE_CHANNEL, gfdm::EST_FILTERED, filtered, estimate, nframes);
 }
 
 int gfdm_hip_channel_estimator_interpolate_frame_device(gfdm_hip_channel_estimator* c, void* frame_estimate, const void* filtered, int64_t nframes,
                                                         void* stream)
 {
-    return est_run_device(c, gfdm::EST_FILTERED, gfdm::EST_FRAME, 0, frame_estimate, filtered, nframes, stream);
+    return est_run_device(c, gfdm::EST_FILTERED, gfdm::EST_FRAME, frame_estimate, filtered, nframes, stream);
 }
 
 int gfdm_hip_channel_estimator_interpolate_frame_host(gfdm_hip_channel_estimator* c, float* frame_estimate, const float* filtered, int64_t nframes)
 {
-    return est_run_host(c, gfdm::EST_FILTERED, gfdm::EST_FRAME, 0, frame_estimate, filtered, nframes);
+    return est_run_host(c, gfdm::EST_FILTERED, gfdm::EST_FRAME, frame_estimate, filtered, nframes);
 }
 
 int gfdm_hip_channel_estimator_prepare_for_zf_device(gfdm_hip_channel_estimator* c, void* transformed_frame, const void* frame_estimate,

@@ -111,9 +111,11 @@ enum EqSource {
 enum EstStage { EST_RX_PREAMBLE = 0, EST_PREAMBLE_CHANNEL = 1, EST_FILTERED = 2, EST_FRAME = 3 };
 size_t estimator_lds_bytes(int K);
 bool estimator_supports(int K);
-hipError_t launch_estimate(const EstPlan& e, int in_stage, int out_stage, int zf, cf* out, const cf* in, int64_t nframes, hipStream_t s);
+hipError_t launch_estimate(const EstPlan& e, int in_stage, int out_stage, cf* out, const cf* in, int64_t nframes, hipStream_t s);
 hipError_t launch_estimate_snr(const EstPlan& e, float* snr, float* cnrs, const cf* in, int64_t nframes, hipStream_t s);
 hipError_t launch_prepare_for_zf(cf* out, const cf* in, int64_t n, hipStream_t s);
+bool rowlane_supports_estimate(int M, int K);
+hipError_t launch_rowlane_estimate(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s);   // rx preamble -> frame
 
 enum KernelFamily { FAMILY_GENERIC = 0, FAMILY_FAST = 1, FAMILY_ROWLANE = 2 };
 

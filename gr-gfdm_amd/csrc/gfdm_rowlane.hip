@@ -21,7 +21,8 @@ namespace gfdm {
     RX_DECL(rowlane_rx1_##K_##_##M_##_##L_)                                                                                         \
     RX_DECL(rowlane_rx2_##K_##_##M_##_##L_)                                                                                         \
     hipError_t rowlane_mod_##K_##_##M_##_##L_(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in,        \
-                                              int64_t nblocks, hipStream_t s);
+                                              int64_t nblocks, hipStream_t s);                                                      \
+    hipError_t rowlane_est_##K_##_##M_##_##L_(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s);
 GFDM_ROW_SHAPES(X)
 #undef X
 #undef RX_DECL
@@ -32,6 +33,24 @@ bool rowlane_supports(int M, int K, int L)
     GFDM_ROW_SHAPES(X)
 #undef X
     return false;
+}
+
+// the estimator does not depend on the overlap: the first shape with this (K, M)
+bool rowlane_supports_estimate(int M, int K)
+{
+#define X(K_, M_, L_) if (K == K_ && M == M_) return true;
+    GFDM_ROW_SHAPES(X)
+#undef X
+    return false;
+}
+
+hipError_t launch_rowlane_estimate(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s)
+{
+    if (nframes <= 0) return hipSuccess;
+#define X(K_, M_, L_) if (e.K == K_ && e.M == M_) return rowlane_est_##K_##_##M_##_##L_(e, out, in, nframes, s);
+    GFDM_ROW_SHAPES(X)
+#undef X
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_rowlane_modulate(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks,

@@ -597,6 +597,89 @@ hipError_t launch_mod(const DevicePlan& p, const TxParams& tx, const cf* twT, cf
     return hipGetLastError();
 }
 
+// =====================================================================================================================
+// estimate_frame of preamble_channel_estimator_cc (lib/preamble_channel_estimator_cc.cc:284-295) in the row-lane layout: K lanes per
+// received preamble.  Same pieces as the EQ_PREAMBLE path of k_row_receive; the frame estimate of row q (bins M q .. M q + M - 1)
+// is produced in registers, staged through the tile and stored in linear order (coalesced).
+template <int K, int M>
+__global__ __launch_bounds__(RowShape<K>::WG) void k_row_estimate(EstPlan est, cf* __restrict__ out, const cf* __restrict__ in,
+                                                                 int64_t nframes)
+{
+    using S = RowShape<K>;
+    using T = RowTile<K, M>;
+    constexpr int N = K * M;
+    static_assert(N >= 3 * K, "the tile must hold the [K][2] preamble view plus the smoothed estimate");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int g = threadIdx.x / K, q = threadIdx.x - g * K;
+    const int64_t blk = (int64_t)blockIdx.x * S::BPW + g;
+    const bool valid = blk < nframes;
+    cf* X = reinterpret_cast<cf*>(smem) + g * T::TS;
+    cf* inter = reinterpret_cast<cf*>(smem + row_lds_bytes<K, M>()) + g * EstTile<K>::FS;
+    cf* F = X + 2 * K;                                                             // smoothed estimate behind the [K][2] view
+
+    const cf* pre = in + (valid ? blk : 0) * (int64_t)(2 * K);
+    const cf p0 = pre[q], p1 = pre[K + q];
+    const cf inv0 = est.inv0[q], inv1 = est.inv1[q];
+    cf* xa = X + FftLayout<K>::slot(q) * 2;
+    xa[0] = p0;
+    xa[1] = p1;
+    block_sync<K>();
+    lds_subcarrier_fft<K, 2, false>(X, q, est.wK);                                 // both halves           est:118-145
+    const cf eq = cfma(X[2 * q], inv0, cmul(X[2 * q + 1], inv1));
+    const int pos = est_active_pos(q, est), n_est = est.n_est;
+    if (pos >= 0) {                                                                //                       est:147-175
+        inter[4 + pos] = eq;
+        if (pos == 0) { inter[0] = eq; inter[1] = eq; inter[2] = eq; inter[3] = eq; }
+        if (pos == n_est - 1) { inter[n_est + 4] = eq; inter[n_est + 5] = eq; inter[n_est + 6] = eq; inter[n_est + 7] = eq; }
+    }
+    block_sync<K>();
+    if (est.dc_free) {
+        if (q == 0) {
+            const cf lo = inter[4 + est.A / 2 - 1], hi = inter[4 + est.A / 2 + 1];
+            inter[4 + est.A / 2] = mk(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y));
+        }
+        block_sync<K>();
+    }
+    if (q < n_est) {                                                               // 9-tap Gaussian         est:176-187
+        cf acc = mk(0.f, 0.f);
+        static_for<0, 9>([&](auto ti) {
+            constexpr int t = decltype(ti)::value;
+            const cf x = inter[q + t];
+            acc.x += x.x * est.gauss[t];
+            acc.y += x.y * est.gauss[t];
+        });
+        F[q] = acc;
+    }
+    block_sync<K>();
+    cf lo, hi;                                                                     //                       est:238-273
+    est_row_segment(F, 1, q, est, lo, hi);
+    block_sync<K>();                                                               // every lane has its end points: the tile is free
+    const cf dlt = mk(hi.x - lo.x, hi.y - lo.y);
+    constexpr float step = 1.0f / (float)M;
+    static_for<0, M>([&](auto mi) {
+        constexpr int m = decltype(mi)::value;
+        const float t = (float)m * step;
+        X[q * M + m] = mk(lo.x + dlt.x * t, lo.y + dlt.y * t);
+    });
+    block_sync<K>();
+    if (valid) {
+        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; out[blk * N + q + K * i] = X[q + K * i]; });
+    }
+}
+
+template <int K, int M>
+hipError_t launch_est(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t st)
+{
+    constexpr size_t lds = row_lds_bytes<K, M>() + EstTile<K>::bytes;
+    const dim3 grid((unsigned)((nframes + RowShape<K>::BPW - 1) / RowShape<K>::BPW)), block(RowShape<K>::WG);
+    if (lds > 64 * 1024) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(k_row_estimate<K, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL((k_row_estimate<K, M>), grid, block, lds, st, e, out, in, nframes);
+    return hipGetLastError();
+}
+
 }  // namespace
 }  // namespace gfdm
 
@@ -616,6 +699,10 @@ hipError_t launch_mod(const DevicePlan& p, const TxParams& tx, const cf* twT, cf
                                               int64_t nblocks, hipStream_t s)                                                       \
     {                                                                                                                               \
         return launch_mod<K_, M_, L_>(p, tx, twT, out, in, nblocks, s);                                                             \
+    }                                                                                                                               \
+    hipError_t rowlane_est_##K_##_##M_##_##L_(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s)              \
+    {                                                                                                                               \
+        return launch_est<K_, M_>(e, out, in, nframes, s);                                                                          \
     }                                                                                                                               \
     }
 // argument macros (-DGFDM_SHAPE_K=..) must be expanded before they are pasted into the function names

@@ -111,6 +111,7 @@ def lib():
         "gfdm_hip_channel_estimator_frame_len": (i32, [vp]),
         "gfdm_hip_channel_estimator_is_dc_free": (i32, [vp]),
         "gfdm_hip_channel_estimator_filtered_len": (i32, [vp]),
+        "gfdm_hip_channel_estimator_kernel_name": (cp, [vp]),
         "gfdm_hip_channel_estimator_preamble_filter_taps": (i32, [vp, vp]),
         "gfdm_hip_channel_estimator_estimate_frame_host": (i32, [vp, vp, vp, i64]),
         "gfdm_hip_channel_estimator_estimate_frame_device": (i32, [vp, vp, vp, i64, vp]),
@@ -600,6 +601,9 @@ class ChannelEstimator(_Kernel):
 
     def filtered_len(self):
         return lib().gfdm_hip_channel_estimator_filtered_len(self._h)
+
+    def kernel_name(self):
+        return lib().gfdm_hip_channel_estimator_kernel_name(self._h).decode()
 
     def preamble_filter_taps(self):
         out = np.empty(9, np.float32)

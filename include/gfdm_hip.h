@@ -194,6 +194,7 @@ int gfdm_hip_channel_estimator_active_subcarriers(const gfdm_hip_channel_estimat
 int gfdm_hip_channel_estimator_frame_len(const gfdm_hip_channel_estimator* c);            /* .h:59, timeslots * fft_len */
 int gfdm_hip_channel_estimator_is_dc_free(const gfdm_hip_channel_estimator* c);           /* .h:61 */
 int gfdm_hip_channel_estimator_filtered_len(const gfdm_hip_channel_estimator* c);         /* active_subcarriers + is_dc_free */
+const char* gfdm_hip_channel_estimator_kernel_name(const gfdm_hip_channel_estimator* c);  /* kernel family of estimate_frame */
 int gfdm_hip_channel_estimator_preamble_filter_taps(const gfdm_hip_channel_estimator* c, float* out);   /* .h:62, 9 floats; returns 9 */
 /* estimate_frame (lib/preamble_channel_estimator_cc.cc:284-295): the three stages below fused.  Bins the reference leaves
  * unwritten when not dc-free ([(A/2 - 1) M, (A/2) M)) carry the value of the constant region next to them. */

@@ -30,6 +30,7 @@ def test_estimate_frame_matches_pygfdm(name):
     M, K, A = g["M"], g["K"], g["A"]
     est = gfdm_amd.ChannelEstimator(M, K, A, True, 1, g["preamble"])
     assert (est.timeslots(), est.fft_len(), est.active_subcarriers(), est.frame_len(), est.is_dc_free()) == (M, K, A, M * K, True)
+    assert est.kernel_name() == ("rowlane" if (K, M) in ((64, 9), (128, 15)) else "generic_lds")      # both families are exercised
     got = est.estimate_frame(g["rx_preambles"])
     assert got.shape == g["pygfdm_frame_estimates"].shape
     assert rel_err(got, g["pygfdm_frame_estimates"]) < TOL
@@ -72,6 +73,23 @@ def test_estimator_stages_against_oracle(M, K, A, dc_free):
         written = np.ones(M * K, bool)
         written[(A // 2 - 1) * M:(A // 2) * M] = False
         assert rel_err(fused[:, written], ref_i[:, written]) < TOL
+
+
+def test_estimate_frame_families_agree(monkeypatch):
+    """row-lane estimate_frame == generic estimate_frame (same device functions, different FFT) on a big ragged batch."""
+    import gfdm_amd
+    rng = np.random.default_rng(9)
+    for (M, K, A, dc_free) in ((9, 64, 52, True), (5, 32, 24, False), (31, 256, 220, True)):
+        pre = (rng.standard_normal(2 * K) + 1j * rng.standard_normal(2 * K)) / np.sqrt(2)
+        rx = rng.standard_normal((1031, 2 * K)) + 1j * rng.standard_normal((1031, 2 * K))
+        fast = gfdm_amd.ChannelEstimator(M, K, A, dc_free, 1, pre)
+        monkeypatch.setenv("GFDM_HIP_FAMILY", "generic")
+        slow = gfdm_amd.ChannelEstimator(M, K, A, dc_free, 1, pre)
+        monkeypatch.delenv("GFDM_HIP_FAMILY")
+        assert (fast.kernel_name(), slow.kernel_name()) == ("rowlane", "generic_lds")
+        a, b = fast.estimate_frame(rx), slow.estimate_frame(rx)
+        assert rel_err(a, b) < 1e-5
+        assert rel_err(a, R.estimate_frame(rx, pre, M, K, A, dc_free)) < 1e-5
 
 
 def test_estimator_feeds_zero_forcing_receiver_on_device():
