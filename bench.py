@@ -252,7 +252,7 @@ def main():
                      # copy kernel of the same access shape] + WRITE_SIZE; profiles/r01/pmc_hbm_traffic_summary.csv).
                      # Counters cannot be read from inside this process, so the figure is only quoted for the
                      # configuration it was measured on.
-                     "traffic": (18567 + 18432) * 1024 if (B == 4096 and dem.kernel_name() == "rowlane") else None,
+                     "traffic": (18576 + 18432) * 1024 if (B == 4096 and dem.kernel_name() == "rowlane") else None,
                      "kernel": dem.kernel_name() + " (demodulate, MF)", "bytes_per_launch": 16 * N * B,
                      "kernel_ms": kern_ms,
                      "region": "single-stream replay of the %d timed steps' demodulate launches back to back, one HIP event pair around "

@@ -1,0 +1,17 @@
+"""Summarise rocprofv3 --pmc CSV output: per (run, counter, kernel) launches, mean / min / max in KiB.
+usage: pmc_summary.py <dir with */*counter_collection.csv, run name = first directory component>"""
+import csv, glob, os, re, sys
+from collections import defaultdict
+root = sys.argv[1]
+acc = defaultdict(list)
+for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+    run = os.path.relpath(f, root).split(os.sep)[0]
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].replace("gfdm::(anonymous namespace)::", "").replace("void ", "")
+        name = re.sub(r"\(.*$", "", name)
+        acc[(run, r["Counter_Name"], name)].append(float(r["Counter_Value"]))
+w = csv.writer(sys.stdout)
+w.writerow(["run", "counter", "kernel", "launches", "mean_KiB", "min_KiB", "max_KiB"])
+for (run, c, k), v in sorted(acc.items()):
+    if k.startswith(("k_", "copy_")):
+        w.writerow([run, c, k, len(v), "%.2f" % (sum(v) / len(v)), "%.2f" % min(v), "%.2f" % max(v)])

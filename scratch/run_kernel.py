@@ -19,6 +19,16 @@ for s in range(slots):
     sym = synth.qpsk_symbols(s * B, B, N, dev)
     x = mod.modulate(sym); f = synth.channel_response(s * B, B, N, dev); xe = synth.through_channel(x, f)
     ins.append((sym, x, xe)); eqs.append(f); outs.append(torch.empty_like(x))
+if path in ("frames_zf_ic2_est", "estimate_frame"):      # channel estimator, stand-alone / fused in front of ZF + 2 IC + demapper (52 active)
+    A = (52 * K) // 64
+    smap = np.concatenate((np.arange(1, A // 2 + 1), np.arange(K - A // 2, K)))
+    pre = np.tile(np.fft.ifft(np.exp(2j * np.pi * np.random.default_rng(0).random(K))) * np.sqrt(K), 2)
+    est = gfdm_amd.ChannelEstimator(M, K, A, True, 1, pre)
+    advf = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, 2, qpsk)
+    advf.configure_frames(N, 0, smap, True)
+    advf.set_channel_estimator(est)
+    rxp = [torch.tensor(np.tile(pre, (B, 1)), dtype=torch.complex64, device=dev) + 0.05 * torch.randn(B, 2 * K, dtype=torch.complex64, device=dev) for _ in range(slots)]
+    souts = [torch.empty(B, A * M, dtype=torch.complex64, device=dev) for _ in range(slots)]
 torch.cuda.synchronize()
 for r in range(reps):
     s = r % slots
@@ -28,5 +38,7 @@ for r in range(reps):
     elif path == "demod_zf": dem.demodulate_equalize(xe, eqs[s], out=outs[s])
     elif path == "demod_mf_ic2": adv.demodulate(x, out=outs[s])
     elif path == "demod_zf_ic2": adv.demodulate_equalize(xe, eqs[s], out=outs[s])
+    elif path == "frames_zf_ic2_est": advf.demodulate_estimated(x, rxp[s], out=souts[s])
+    elif path == "estimate_frame": est.estimate_frame(rxp[s])
 torch.cuda.synchronize()
 print("done", path, B, reps)
