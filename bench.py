@@ -273,7 +273,7 @@ def main():
             _, _, wmax = sharding.reduce_stats(0, torch.zeros(3, dtype=torch.float64, device=dev), w, dev)
             gbps = bytes_per_sym * N * B / (kms * 1e-3) / 1e9
             paths[name] = {"blocks_per_s": world * B * a.steps / wmax, "msym_per_s": world * B * a.steps / wmax * N / 1e6,
-                           "kernel_ms": kms, "bytes_per_launch": bytes_per_sym * N * B, "achieved_GBps": gbps,
+                           "kernel_ms": kms, "bytes_per_launch": int(round(bytes_per_sym * N * B)), "achieved_GBps": gbps,
                            "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "ring_slots": n_slots}
             del keep
 
@@ -306,6 +306,34 @@ def main():
         measure("demod_zf", 3, 24, mk_rx(L_.gfdm_hip_receiver_demodulate_device, dem._h, True))
         measure("demod_mf_ic2", 2, 16, mk_rx(L_.gfdm_hip_advanced_receiver_work_device, adv._h, False))
         measure("demod_zf_ic2", 3, 24, mk_rx(L_.gfdm_hip_advanced_receiver_work_device, adv._h, True))
+
+        # the receive chain of examples/hier_gfdm_receiver.grc in ONE kernel: channel estimate from each frame's received
+        # preamble + ZF + 2 IC + resource demapper (52 of 64 subcarriers active): 8 N + 16 K bytes read, 8 A M written per frame
+        A_ = (52 * K) // 64
+        smap_ = np.concatenate((np.arange(1, A_ // 2 + 1), np.arange(K - A_ // 2, K)))
+        pre_ = np.tile(np.fft.ifft(np.exp(2j * np.pi * np.random.default_rng(0).random(K))) * np.sqrt(K), 2)
+        est_ = gfdm_amd.ChannelEstimator(M, K, A_, True, 1, pre_, device=local)
+        advf = gfdm_amd.AdvancedReceiver(M, K, L, np.conj(taps), smap_, 2, qpsk, device=local)
+        advf.configure_frames(N, 0, smap_, True)
+        advf.set_channel_estimator(est_)
+
+        def mk_chain(n_slots):
+            fr, _ = rx_inputs(n_slots, False)
+            rp = [torch.tensor(np.tile(pre_, (B, 1)), dtype=torch.complex64, device=dev) for _ in range(n_slots)]
+            o = [torch.empty(B, A_ * M, dtype=torch.complex64, device=dev) for _ in range(n_slots)]
+
+            def launcher(s):
+                args = [advf._h, ctypes.c_void_p(o[s].data_ptr()), ctypes.c_void_p(fr[s].data_ptr()), ctypes.c_void_p(rp[s].data_ptr()),
+                        ctypes.c_int(0), ctypes.c_int(-1), ctypes.c_int64(B), ctypes.c_void_p(stream)]
+
+                def go():
+                    rc = L_.gfdm_hip_advanced_receiver_work_estimated_device(*args)
+                    if rc != 0:
+                        raise RuntimeError("gfdm_hip launch failed: %d" % rc)
+                return go
+            return [[launcher(s)] for s in range(n_slots)], (fr, rp, o)
+
+        measure("frames_zf_ic2_estimated", 2, (8.0 * N + 16.0 * K + 8.0 * A_ * M) / N, mk_chain)
         result["paths"] = paths
         result["north_star"] = {"path": "demod_zf_ic2 (BASELINE configs[2]: ZF demod + 2 IC iterations)",
                                 "frac_of_hbm_peak": paths["demod_zf_ic2"]["frac_of_hbm_peak"], "target": 0.40}
