@@ -409,20 +409,26 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                 static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; nb[m] = below[m] + above[m]; });
             }
             if constexpr (ICSYM) {
+                // real symmetric kernel: both components of a term share the real factor -> one packed v_pk_fma_f32 per term
+                // (and one v_pk_add_f32 per symmetric pair)
+                typedef float v2f __attribute__((ext_vector_type(2)));
                 constexpr int H = (M - 1) / 2;
+                v2f nv[M];
+                static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; nv[m] = v2f{ nb[m].x, nb[m].y }; });
                 static_for<0, M>([&](auto pi) {
                     constexpr int pp = decltype(pi)::value;
-                    cf acc = mk(fmaf(-p.icg[0].x, nb[pp].x, d0[pp].x), fmaf(-p.icg[0].x, nb[pp].y, d0[pp].y));
+                    const float g0 = -p.icg[0].x;
+                    v2f acc = __builtin_elementwise_fma(nv[pp], v2f{ g0, g0 }, v2f{ d0[pp].x, d0[pp].y });
                     static_for<1, H + 1>([&](auto ri) {
                         constexpr int r = decltype(ri)::value;
-                        const cf pair = nb[(pp - r + M) % M] + nb[(pp + r) % M];
-                        acc = mk(fmaf(-p.icg[r].x, pair.x, acc.x), fmaf(-p.icg[r].x, pair.y, acc.y));
+                        const float gr = -p.icg[r].x;
+                        acc = __builtin_elementwise_fma(nv[(pp - r + M) % M] + nv[(pp + r) % M], v2f{ gr, gr }, acc);
                     });
                     if constexpr (M % 2 == 0) {
-                        const cf mid = nb[(pp + M / 2) % M];
-                        acc = mk(fmaf(-p.icg[M / 2].x, mid.x, acc.x), fmaf(-p.icg[M / 2].x, mid.y, acc.y));
+                        const float gm = -p.icg[M / 2].x;
+                        acc = __builtin_elementwise_fma(nv[(pp + M / 2) % M], v2f{ gm, gm }, acc);
                     }
-                    d[pp] = acc;
+                    d[pp] = mk(acc.x, acc.y);
                 });
             } else {
                 static_for<0, M>([&](auto pi) {
