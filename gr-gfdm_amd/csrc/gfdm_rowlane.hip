@@ -9,7 +9,11 @@
     X(32, 5, 2)            \
     X(32, 9, 2)            \
     X(128, 15, 4)          \
-    X(256, 31, 2)
+    X(256, 31, 2)          \
+    X(64, 5, 2)            \
+    X(64, 15, 2)           \
+    X(128, 9, 2)           \
+    X(128, 15, 2)
 
 namespace gfdm {
 

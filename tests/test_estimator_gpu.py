@@ -30,7 +30,7 @@ def test_estimate_frame_matches_pygfdm(name):
     M, K, A = g["M"], g["K"], g["A"]
     est = gfdm_amd.ChannelEstimator(M, K, A, True, 1, g["preamble"])
     assert (est.timeslots(), est.fft_len(), est.active_subcarriers(), est.frame_len(), est.is_dc_free()) == (M, K, A, M * K, True)
-    assert est.kernel_name() == ("rowlane" if (K, M) in ((64, 9), (128, 15)) else "generic_lds")      # both families are exercised
+    assert est.kernel_name() == ("rowlane" if (K, M) in ((64, 9), (128, 15), (64, 5)) else "generic_lds")      # both families are exercised
     got = est.estimate_frame(g["rx_preambles"])
     assert got.shape == g["pygfdm_frame_estimates"].shape
     assert rel_err(got, g["pygfdm_frame_estimates"]) < TOL
@@ -188,7 +188,7 @@ def test_estimator_pybind_surface():
         gfdm_python.Preamble_channel_estimator(M, K, A, True, 1, g["preamble"][:100])
 
 
-@pytest.mark.parametrize("M,K,L,A,dc_free", [(9, 64, 2, 52, True), (5, 32, 2, 24, True), (9, 32, 2, 28, False), (15, 128, 4, 110, True),
+@pytest.mark.parametrize("M,K,L,A,dc_free", [(9, 64, 2, 52, True), (5, 64, 2, 52, True), (15, 128, 2, 110, False), (5, 32, 2, 24, True), (9, 32, 2, 28, False), (15, 128, 4, 110, True),
                                              (31, 256, 2, 220, True), (7, 12, 2, 8, True), (3, 48, 2, 40, False)])
 def test_receivers_with_fused_estimator(M, K, L, A, dc_free):
     """demodulate_estimated == estimate_frame followed by demodulate_equalize (the oracle's chain), for the plain receiver and the

@@ -22,7 +22,8 @@ DECISION_GUARD = 1e-4
 # (M, K, L, alpha): BASELINE.json configs 1-5 and the shapes of the reference's tests
 SHAPES = [(5, 32, 2, 0.5), (9, 64, 2, 0.2), (15, 128, 4, 0.2), (31, 256, 2, 0.1),
           (16, 4, 2, 0.35), (21, 128, 2, 0.35), (8, 4, 2, 0.5), (127, 16, 4, 0.5), (127, 16, 2, 0.5), (9, 32, 2, 0.5),
-          (25, 96, 2, 0.35), (7, 6, 2, 0.3), (3, 10, 6, 0.3), (4, 16, 3, 0.4)]
+          (25, 96, 2, 0.35), (7, 6, 2, 0.3), (3, 10, 6, 0.3), (4, 16, 3, 0.4),
+          (5, 64, 2, 0.5), (15, 64, 2, 0.2), (9, 128, 2, 0.2), (15, 128, 2, 0.35)]     # further row-lane shapes (reference demos / tests)
 
 
 @pytest.fixture(scope="module", autouse=True)
