@@ -101,10 +101,10 @@ def timed_loop(step_fns, dominant, steps, warmup, world, time_kernel=True):
     if time_kernel:
         e1.record()
     torch.cuda.synchronize()
+    wall = time.perf_counter() - t0           # this rank's time for its K steps; the caller takes the MAX over ranks
     if world > 1:
-        dist.barrier()
+        dist.barrier()                        # closing bracket: every rank has finished before anyone moves on
     torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
     kern_ms = None
     if time_kernel:
         if len(step_fns[0]) > 1:          # several kernels per step: replay only the dominant one over the same ring slots
