@@ -22,6 +22,7 @@ Beside the headline the JSON line carries
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
 import sys
@@ -88,6 +89,8 @@ def timed_loop(step_fns, dominant, steps, warmup, world, time_kernel=True):
         for f in step_fns[i % nslots]:
             f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gc.collect()
+    gc.disable()                              # no collector pause (tens of ms with the tensor rings alive) inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -102,6 +105,7 @@ def timed_loop(step_fns, dominant, steps, warmup, world, time_kernel=True):
         e1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0           # this rank's time for its K steps; the caller takes the MAX over ranks
+    gc.enable()
     if world > 1:
         dist.barrier()                        # closing bracket: every rank has finished before anyone moves on
     torch.cuda.synchronize()

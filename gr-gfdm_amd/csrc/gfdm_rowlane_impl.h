@@ -262,6 +262,8 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     // The equaliser vector is needed only after the subcarrier FFT: request it now, behind every wave's sample loads
     // (HBM serves requests roughly in issue order, so the samples of all waves arrive first and the transforms start
     // earlier; f_eq streams in while phases A/B run).
+    constexpr bool ROWREG = (K == 64 && L == 2 && EQ == EQ_PREAMBLE);   // equalised row stays in registers between phases C and D
+    cf xrow[ROWREG ? M : 1];
     cf heq[EQ == EQ_VECTOR ? M : 1];
     if constexpr (EQ == EQ_VECTOR) {
 #ifndef GFDM_EAGER_FEQ
@@ -324,22 +326,37 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
             const float t = (float)m * step;
             const cf a = X[q * MS + m], b = mk(lo.x + dlt.x * t, lo.y + dlt.y * t);
             const float inv = __builtin_amdgcn_rcpf(b.x * b.x + b.y * b.y);
-            X[q * MS + m] = mk((a.x * b.x + a.y * b.y) * inv, (a.y * b.x - a.x * b.y) * inv);
+            const cf e = mk((a.x * b.x + a.y * b.y) * inv, (a.y * b.x - a.x * b.y) * inv);
+            if constexpr (ROWREG) xrow[m] = e; else X[q * MS + m] = e;      // ROWREG: phase D takes the row from registers
         });
-        block_sync<K>();
+        if constexpr (!ROWREG) block_sync<K>();
     }
 
     // ---- phase D: S[k][m] = sum_i taps[((i + L/2) % L) M + m] X[(k + i - L/2) mod K][m]                      rx:165-192
     cf s[M];
     static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = mk(0.f, 0.f); });
-    static_for<0, L>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        const cf* rb = X + ((q + i - L / 2 + K) & (K - 1)) * MS;
+    if constexpr (K == 64 && L == 2) {
+        // the block IS the wavefront and the only foreign row is k - 1 = lane k - 1: a DPP wave rotate of the own row replaces the
+        // second LDS row read
+        const cf* rb = X + q * MS;
         static_for<0, M>([&](auto mi) {
             constexpr int m = decltype(mi)::value;
-            s[m] = cfma(p.taps[((i + L / 2) % L) * M + m], rb[m], s[m]);
+            cf own;
+            if constexpr (ROWREG) own = xrow[m]; else own = rb[m];
+            const cf below = mk(dpp_wave_ror1(own.x), dpp_wave_ror1(own.y));
+            s[m] = cfma(p.taps[M + m], below, s[m]);                                   // i = 0: row k - 1
+            s[m] = cfma(p.taps[m], own, s[m]);                                         // i = 1: row k
         });
-    });
+    } else {
+        static_for<0, L>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const cf* rb = X + ((q + i - L / 2 + K) & (K - 1)) * MS;
+            static_for<0, M>([&](auto mi) {
+                constexpr int m = decltype(mi)::value;
+                s[m] = cfma(p.taps[((i + L / 2) % L) * M + m], rb[m], s[m]);
+            });
+        });
+    }
     constexpr float invM = 1.0f / (float)M;
     cf d[M];
     if constexpr (MODE != RX_FD) {
