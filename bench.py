@@ -363,8 +363,19 @@ def main():
             nst = max(10, a.steps // 8)
             w, kms = timed_loop(fns, 0, nst, 3, world)
             _, _, wmax = sharding.reduce_stats(0, torch.zeros(3, dtype=torch.float64, device=dev), w, dev)
+            # beside the back-to-back mean, the median of per-launch event pairs: a sustained run of launches of this size makes some
+            # boxes of the pool drop their clocks after a few milliseconds (power cap), and idle gaps make them ramp down as well, so
+            # the two figures bracket the kernel's duration
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nst)]
+            for i in range(nst):
+                evs[i][0].record()
+                fns[i % nsl][0]()
+                evs[i][1].record()
+            torch.cuda.synchronize()
+            kms_med = float(np.median([x.elapsed_time(y) for x, y in evs]))
             gbps = bps * N * BL / (kms * 1e-3) / 1e9
             large[name] = {"blocks_per_launch": BL, "blocks_per_s": world * BL * nst / wmax, "kernel_ms": kms,
+                           "kernel_ms_per_launch_median": kms_med,
                            "bytes_per_launch": bps * N * BL, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
             del fr, eq, o, fns
         result["large_batch"] = large
