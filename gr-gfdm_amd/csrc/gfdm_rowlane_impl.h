@@ -119,8 +119,32 @@ template <int K> struct FftLayout {
 // pulls its 4 x CMAX inputs into registers, a barrier separates the reads from the (autosort-permuted) writes.
 // One tile instead of a ping-pong pair halves the LDS footprint, i.e. doubles the resident waves per CU.
 // Input rows are expected at FftLayout<K>::slot(row); the result is in natural row order.
+// Twiddles of the radix-4 passes, per lane: three roots for every pass but the last.  They are fetched ONCE, early in the kernel
+// (next to the sample loads): loaded inside the passes, each pass would wait for a vector-memory round trip between its LDS reads
+// and writes, because loads cannot be hoisted across the ordering points.
+template <int K> struct FftTwiddles {
+    cf w[RowShape<K>::NP4][3];
+};
+
+template <int K>
+__device__ __forceinline__ void load_fft_twiddles(FftTwiddles<K>& t, int lane, const cf* __restrict__ wK)
+{
+    using S = RowShape<K>;
+    const int tq = lane % S::RG;
+    static_for<0, S::NP4>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        constexpr int str = pow4(s), ms = K / str / 4;
+        if constexpr (ms > 1) {
+            const int qq = tq / str;
+            t.w[s][0] = wK[(qq * str) & (K - 1)];
+            t.w[s][1] = wK[(qq * 2 * str) & (K - 1)];
+            t.w[s][2] = wK[(qq * 3 * str) & (K - 1)];
+        }
+    });
+}
+
 template <int K, int M, bool INV>
-__device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const cf* __restrict__ wK)
+__device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const FftTwiddles<K>& twd)
 {
     using S = RowShape<K>;
     using LY = FftLayout<K>;
@@ -134,11 +158,7 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const cf*
         constexpr bool last = (s == S::NP4 - 1) && !S::HAS2;      // the pass that leaves the data in natural order
         const int j = tq & (str - 1), qq = tq / str;
         cf w1, w2, w3;
-        if constexpr (ms > 1) {
-            w1 = wK[(qq * str) & (K - 1)];
-            w2 = wK[(qq * 2 * str) & (K - 1)];
-            w3 = wK[(qq * 3 * str) & (K - 1)];
-        }
+        if constexpr (ms > 1) { w1 = twd.w[s][0]; w2 = twd.w[s][1]; w3 = twd.w[s][2]; }
         cf* wb[4];
         static_for<0, 4>([&](auto ui) {
             constexpr int u = decltype(ui)::value;
@@ -239,6 +259,8 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     // ---- phase A: timeslot DFT of row q, twiddle W_N^{q m}
     cf v[M];
     static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = in[in_base + K * pp + q]; });
+    FftTwiddles<K> twd;
+    load_fft_twiddles<K>(twd, q, p.wK);
     GFDM_STAMP(1);
     // EQ_PREAMBLE: the received preamble's two halves ride through the subcarrier FFT as columns M and M + 1 of the tile
     cf pre0, pre1, inv0, inv1;
@@ -273,7 +295,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     }
 
     // ---- phase B: subcarrier FFT, in place
-    lds_subcarrier_fft<K, MS, false>(X, q, p.wK);
+    lds_subcarrier_fft<K, MS, false>(X, q, twd);
 
     GFDM_STAMP(2);
     // ---- phase C: X[f] / f_eq[f] in linear order (a conj(b) / |b|^2, reciprocal by v_rcp_f32)              rx:315-316
@@ -506,6 +528,8 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
     const int64_t base = (valid ? blk : 0) * N;
     cf* X = reinterpret_cast<cf*>(smem) + g * T::TS;
 
+    FftTwiddles<K> twd;
+    load_fft_twiddles<K>(twd, q, p.wK);
     cf v[M];
     if constexpr (TXMODE == 0) {
         // symbols [k][p], copied linearly (coalesced) into the tile; lane k then owns row k
@@ -552,7 +576,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
         static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = scale(v[m], invN); });
     }
     block_sync<K>();
-    lds_subcarrier_fft<K, M, true>(X, q, p.wK);                                                         // inverse over j
+    lds_subcarrier_fft<K, M, true>(X, q, twd);                                                          // inverse over j
     v[0] = X[q * M];
     static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = cmulc(X[q * M + m], twT[m * K + q]); });
     dft_inplace<M, true>(v);                                                                           // mod:137-140
@@ -643,11 +667,13 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_estimate(EstPlan est, c
     const cf* pre = in + (valid ? blk : 0) * (int64_t)(2 * K);
     const cf p0 = pre[q], p1 = pre[K + q];
     const cf inv0 = est.inv0[q], inv1 = est.inv1[q];
+    FftTwiddles<K> twd;
+    load_fft_twiddles<K>(twd, q, est.wK);
     cf* xa = X + FftLayout<K>::slot(q) * 2;
     xa[0] = p0;
     xa[1] = p1;
     block_sync<K>();
-    lds_subcarrier_fft<K, 2, false>(X, q, est.wK);                                 // both halves           est:118-145
+    lds_subcarrier_fft<K, 2, false>(X, q, twd);                                    // both halves           est:118-145
     const cf eq = cfma(X[2 * q], inv0, cmul(X[2 * q + 1], inv1));
     const int pos = est_active_pos(q, est), n_est = est.n_est;
     if (pos >= 0) {                                                                //                       est:147-175
