@@ -261,6 +261,19 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = in[in_base + K * pp + q]; });
     FftTwiddles<K> twd;
     load_fft_twiddles<K>(twd, q, p.wK);
+    // Everything else the later phases read from global memory is requested here as well: behind an ordering point a load can
+    // only be issued where it is needed, and its round trip (scalar cache for the uniform tables, L1 / L2 for the per-lane
+    // ones) lands on the wave's critical path.  Filter and IC taps are uniform (SGPRs) and only preloaded while they fit.
+    constexpr bool PRE_TAPS = (L * M <= 24);
+    cf tapv[PRE_TAPS ? L * M : 1], icgv[(PRE_TAPS && MODE == RX_IC) ? M : 1];
+    if constexpr (PRE_TAPS) {
+        static_for<0, L * M>([&](auto ii) { constexpr int i = decltype(ii)::value; tapv[i] = p.taps[i]; });
+        if constexpr (MODE == RX_IC) static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; icgv[i] = p.icg[i]; });
+    }
+    auto tap = [&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (PRE_TAPS) return tapv[i]; else return p.taps[i]; };
+    auto icg = [&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (PRE_TAPS && MODE == RX_IC) return icgv[i]; else return p.icg[i]; };
+    const int wgt = (MODE == RX_IC) ? ic.active[q] : 0;      // multiplicity of subcarrier k in subcarrier_map (0 = inactive)
+    const int rank_q = (MODE != RX_FD && ic.io.demap) ? ic.io.rank[q] : -1;
     GFDM_STAMP(1);
     // EQ_PREAMBLE: the received preamble's two halves ride through the subcarrier FFT as columns M and M + 1 of the tile
     cf pre0, pre1, inv0, inv1;
@@ -366,8 +379,8 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
             cf own;
             if constexpr (ROWREG) own = xrow[m]; else own = rb[m];
             const cf below = mk(dpp_wave_ror1(own.x), dpp_wave_ror1(own.y));
-            s[m] = cfma(p.taps[M + m], below, s[m]);                                   // i = 0: row k - 1
-            s[m] = cfma(p.taps[m], own, s[m]);                                         // i = 1: row k
+            s[m] = cfma(tap(std::integral_constant<int, M + m>{}), below, s[m]);       // i = 0: row k - 1
+            s[m] = cfma(tap(std::integral_constant<int, m>{}), own, s[m]);             // i = 1: row k
         });
     } else {
         static_for<0, L>([&](auto ii) {
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
             const cf* rb = X + ((q + i - L / 2 + K) & (K - 1)) * MS;
             static_for<0, M>([&](auto mi) {
                 constexpr int m = decltype(mi)::value;
-                s[m] = cfma(p.taps[((i + L / 2) % L) * M + m], rb[m], s[m]);
+                s[m] = cfma(tap(std::integral_constant<int, ((i + L / 2) % L) * M + m>{}), rb[m], s[m]);
             });
         });
     }
@@ -394,7 +407,6 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
         // Both transforms are linear, so  d_new = d0 - g (*) nb  with d0 = IDFT_M(S)/M (already in d) and the M-tap circular
         // convolution kernel g = IDFT_M(ic)/M (host table p.icg).  For the usual real, even prototype filters ic is real and
         // symmetric, hence g is too (ICSYM): M(M+1)/2 packed multiply-adds per row and round instead of two M-point DFTs.
-        const int wgt = ic.active[q];                     // multiplicity of subcarrier k in subcarrier_map (0 = inactive)
         float* red = reinterpret_cast<float*>(reinterpret_cast<cf*>(smem) + S::BPW * T::TS);
         cf d0[M];
         static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d0[m] = d[m]; });
@@ -456,15 +468,15 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                 static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; nv[m] = v2f{ nb[m].x, nb[m].y }; });
                 static_for<0, M>([&](auto pi) {
                     constexpr int pp = decltype(pi)::value;
-                    const float g0 = -p.icg[0].x;
+                    const float g0 = -icg(std::integral_constant<int, 0>{}).x;
                     v2f acc = __builtin_elementwise_fma(nv[pp], v2f{ g0, g0 }, v2f{ d0[pp].x, d0[pp].y });
                     static_for<1, H + 1>([&](auto ri) {
                         constexpr int r = decltype(ri)::value;
-                        const float gr = -p.icg[r].x;
+                        const float gr = -icg(std::integral_constant<int, r>{}).x;
                         acc = __builtin_elementwise_fma(nv[(pp - r + M) % M] + nv[(pp + r) % M], v2f{ gr, gr }, acc);
                     });
                     if constexpr (M % 2 == 0) {
-                        const float gm = -p.icg[M / 2].x;
+                        const float gm = -icg(std::integral_constant<int, M / 2>{}).x;
                         acc = __builtin_elementwise_fma(nv[(pp + M / 2) % M], v2f{ gm, gm }, acc);
                     }
                     d[pp] = mk(acc.x, acc.y);
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                     cf acc = d0[pp];
                     static_for<0, M>([&](auto ri) {
                         constexpr int r = decltype(ri)::value;
-                        const cf g = p.icg[r], x = nb[(pp - r + M) % M];
+                        const cf g = icg(std::integral_constant<int, r>{}), x = nb[(pp - r + M) % M];
                         acc = mk(fmaf(-g.x, x.x, fmaf(g.y, x.y, acc.x)), fmaf(-g.x, x.y, fmaf(-g.y, x.x, acc.y)));
                     });
                     d[pp] = acc;
@@ -489,7 +501,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     if (MODE != RX_FD && ic.io.demap) {
         // resource demapper fused into the store: only active subcarriers, in mapper order; for per-timeslot order the lanes of
         // one timeslot write consecutive output symbols, so no LDS staging is needed                     mapper:91-106,136-163
-        const int a = ic.io.rank[q];
+        const int a = rank_q;
         if (valid && a >= 0) {
             cf* o = out + blk * (int64_t)ic.io.nout;
             static_for<0, M>([&](auto mi) {
@@ -530,6 +542,12 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
 
     FftTwiddles<K> twd;
     load_fft_twiddles<K>(twd, q, p.wK);
+    // the twiddles of the last stage and the (uniform) filter taps are requested up front as well, see k_row_receive
+    constexpr bool PRE_TW = (M <= 16), PRE_TAPS = (L * M <= 24);
+    cf twv[PRE_TW ? M : 1], tapv[PRE_TAPS ? L * M : 1];
+    if constexpr (PRE_TW) static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; twv[m] = twT[m * K + q]; });
+    if constexpr (PRE_TAPS) static_for<0, L * M>([&](auto ii) { constexpr int i = decltype(ii)::value; tapv[i] = p.taps[i]; });
+    auto tap = [&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (PRE_TAPS) return tapv[i]; else return p.taps[i]; };
     cf v[M];
     if constexpr (TXMODE == 0) {
         // symbols [k][p], copied linearly (coalesced) into the tile; lane k then owns row k
@@ -552,8 +570,8 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
             const cf up = mk(dpp_wave_rol1(v[m].x), dpp_wave_rol1(v[m].y));          // D[(j + 1) mod K][m]   (i = 0)
             cf acc = mk(0.f, 0.f);
             if constexpr (m < PART) {
-                acc = cfma(up, p.taps[M + m], acc);
-                acc = cfma(v[m], p.taps[m], acc);                                     // D[j][m]              (i = 1)
+                acc = cfma(up, tap(std::integral_constant<int, M + m>{}), acc);
+                acc = cfma(v[m], tap(std::integral_constant<int, m>{}), acc);                                     // D[j][m]              (i = 1)
             }
             v[m] = acc;
         });
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
             const cf* rb = X + ((q - i + L / 2 + K) & (K - 1)) * M;
             static_for<0, PART>([&](auto mi) {
                 constexpr int m = decltype(mi)::value;
-                v[m] = cfma(rb[m], p.taps[((i + L / 2) % L) * M + m], v[m]);
+                v[m] = cfma(rb[m], tap(std::integral_constant<int, ((i + L / 2) % L) * M + m>{}), v[m]);
             });
         });
     }
@@ -578,7 +596,12 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
     block_sync<K>();
     lds_subcarrier_fft<K, M, true>(X, q, twd);                                                          // inverse over j
     v[0] = X[q * M];
-    static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = cmulc(X[q * M + m], twT[m * K + q]); });
+    static_for<1, M>([&](auto mi) {
+        constexpr int m = decltype(mi)::value;
+        cf w;
+        if constexpr (PRE_TW) w = twv[m]; else w = twT[m * K + q];
+        v[m] = cmulc(X[q * M + m], w);
+    });
     dft_inplace<M, true>(v);                                                                           // mod:137-140
     if (valid) {
         if constexpr (TXMODE == 2) {

@@ -73,7 +73,7 @@ def test_transmitter_device_path_and_oracles_at_batch():
         ref = R.transmit(sym_h[:9], nt, g["M"], g["K"], g["L"], g["smap"], g["per_timeslot"], g["cp"], g["cs"], g["ramp"], g["window"], int(s),
                          g["preambles"][port])
         assert rel_err(got[:9], ref) < TOL
-        assert np.array_equal(tx.add_frame(blocks, int(s)).cpu().numpy(), got)      # same arithmetic, same bits
+        assert rel_err(tx.add_frame(blocks, int(s)).cpu().numpy(), got) < 1e-6       # two kernels, same arithmetic up to instruction scheduling
 
 
 def test_transmitter_generic_family_and_validation():
