@@ -274,6 +274,9 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     auto icg = [&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (PRE_TAPS && MODE == RX_IC) return icgv[i]; else return p.icg[i]; };
     const int wgt = (MODE == RX_IC) ? ic.active[q] : 0;      // multiplicity of subcarrier k in subcarrier_map (0 = inactive)
     const int rank_q = (MODE != RX_FD && ic.io.demap) ? ic.io.rank[q] : -1;
+    // ... and the scalar settings the later phases branch on (kernel arguments, i.e. scalar loads at the point of use otherwise)
+    const int io_demap = ic.io.demap, io_nout = ic.io.nout, io_per_timeslot = ic.io.per_timeslot, io_A = ic.io.A;
+    const int ic_iter = ic.ic_iter, ic_decision = ic.decision, ic_pc = ic.do_phase_compensation;
     GFDM_STAMP(1);
     // EQ_PREAMBLE: the received preamble's two halves ride through the subcarrier FFT as columns M and M + 1 of the tile
     cf pre0, pre1, inv0, inv1;
@@ -410,11 +413,11 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
         float* red = reinterpret_cast<float*>(reinterpret_cast<cf*>(smem) + S::BPW * T::TS);
         cf d0[M];
         static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d0[m] = d[m]; });
-        for (int it = 0; it < ic.ic_iter; ++it) {                                                        // adv:56-76
-            const bool pc = (ic.do_phase_compensation > 0) && (it == 0);
+        for (int it = 0; it < ic_iter; ++it) {                                                           // adv:56-76
+            const bool pc = (ic_pc > 0) && (it == 0);
             float acc = 0.f;
             cf dec[M];
-            if (ic.decision == 1 && !pc) {
+            if (ic_decision == 1 && !pc) {
                 // QPSK hot path (constellation_qpsk::decision_maker: sign tests, zero -> negative point); the per-lane
                 // amplitudes are 0 on inactive subcarriers, so one compare + one select per component           adv:109-123
                 const float sp = (wgt > 0) ? 0.70710678118654752f : 0.f, sn = -sp;
@@ -498,16 +501,16 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     }
 
     GFDM_STAMP(4);
-    if (MODE != RX_FD && ic.io.demap) {
+    if (MODE != RX_FD && io_demap) {
         // resource demapper fused into the store: only active subcarriers, in mapper order; for per-timeslot order the lanes of
         // one timeslot write consecutive output symbols, so no LDS staging is needed                     mapper:91-106,136-163
         const int a = rank_q;
         if (valid && a >= 0) {
-            cf* o = out + blk * (int64_t)ic.io.nout;
+            cf* o = out + blk * (int64_t)io_nout;
             static_for<0, M>([&](auto mi) {
                 constexpr int m = decltype(mi)::value;
-                const int idx = ic.io.per_timeslot ? (m * ic.io.A + a) : (a * M + m);
-                if (idx < ic.io.nout) o[idx] = d[m];
+                const int idx = io_per_timeslot ? (m * io_A + a) : (a * M + m);
+                if (idx < io_nout) o[idx] = d[m];
             });
         }
     } else {
