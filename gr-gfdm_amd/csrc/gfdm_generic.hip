@@ -5,9 +5,9 @@
 // The N = K*M point transform is factored along GFDM's own structure (n = K p + q, f = M j + m):
 //     X[M j + m] = sum_q W_K^{q j} * W_N^{q m} * ( sum_p x[K p + q] W_M^{p m} )
 // i.e. M-point DFTs over the timeslot axis, a twiddle, K-point FFTs over the subcarrier axis.
-// This family uses table-driven direct DFTs for the M axis and a radix-2 Stockham FFT (or a
-// direct DFT when K is not a power of two) for the K axis: it is the shape-agnostic path, the
-// tuned register/LDS family for the benchmark shapes is gfdm_fast.hip.
+// This family uses table-driven direct DFTs for the M axis and a mixed-radix Stockham FFT (any K; a
+// prime K degenerates to the direct DFT) for the K axis: it is the shape-agnostic path, the
+// tuned family for the benchmark shapes is gfdm_rowlane_impl.h.
 //
 // Algorithm restated from (gr-gfdm checkout):
 //   modulator  lib/modulator_kernel_cc.cc:98-141
@@ -54,8 +54,21 @@ __device__ void row_dft(cf* dst, const cf* src, int rows, int M, int rs, int ps,
     }
 }
 
-// K-point transform along the subcarrier axis of a [K][M] LDS tile, all M columns at once.
+// K-point transform along the subcarrier axis of a [K][M] LDS tile, all M columns at once: mixed-radix Stockham autosort
+// (decimation in frequency) for ANY K.  Each pass takes the radix r = 4 while 4 divides the remaining length n, else its
+// smallest prime factor: with stride s (product of the radices so far) and m = n / r,
+//     y[q + s (r p + j)] = W_n^{p j} * sum_k x[q + s (p + m k)] W_r^{j k},     q < s, p < m, j < r
+// (a prime K is one pass of radix K, i.e. the direct DFT).  All roots come from the table wK[i] = exp(-2 pi i / K).
 // Data in `a`, scratch `b`; returns the tile that holds the result.  Caller syncs before.
+__device__ __forceinline__ int next_radix(int n)
+{
+    if ((n & 3) == 0) return 4;
+    if ((n & 1) == 0) return 2;
+    for (int f = 3; f * f <= n; f += 2)
+        if (n % f == 0) return f;
+    return n;
+}
+
 template <bool INV>
 __device__ cf* col_fft(cf* a, cf* b, const DevicePlan& p)
 {
@@ -63,39 +76,54 @@ __device__ cf* col_fft(cf* a, cf* b, const DevicePlan& p)
     const cf* __restrict__ wK = p.wK;
     cf* x = a;
     cf* y = b;
-    if (p.log2K >= 0) {
-        const int nbf = (K >> 1) * M;
-        for (int s = 0; s < p.log2K; ++s) {
-            const int str = 1 << s, half = K >> (s + 1);
-            for (int idx = threadIdx.x; idx < nbf; idx += GT) {
-                const int bf = idx / M, m = idx - bf * M;
-                const int j = bf & (str - 1), qq = bf >> s;
-                const cf u = x[(j + str * qq) * M + m];
-                const cf v = x[(j + str * (qq + half)) * M + m];
-                const cf w = wK[qq << s];                         // W_len^{qq}, len = K >> s
-                const cf d = csub(u, v);
-                y[(j + str * (2 * qq)) * M + m] = cadd(u, v);
-                y[(j + str * (2 * qq + 1)) * M + m] = INV ? cmulj(d, w) : cmul(d, w);
+    int n = K, s = 1;
+    while (n > 1) {
+        const int r = next_radix(n), m = n / r;
+        const int rstep = K / r;                                  // W_r^1 = wK[K / r]
+        const int total = m * s * M;                              // (butterfly, column) pairs of this pass
+        for (int idx = threadIdx.x; idx < total; idx += GT) {
+            const int bf = idx / M, col = idx - bf * M;
+            const int q = bf % s, pp = bf / s;
+            const cf* xin = x + (q + s * pp) * M + col;           // element k at xin[s m k M]
+            cf* yout = y + (q + s * r * pp) * M + col;            // element j at yout[s j M]
+            const int in_step = s * m * M, out_step = s * M;
+            if (r == 4) {
+                const cf x0 = xin[0], x1 = xin[in_step], x2 = xin[2 * in_step], x3 = xin[3 * in_step];
+                const cf apc = cadd(x0, x2), amc = csub(x0, x2), bpd = cadd(x1, x3), t = csub(x1, x3);
+                const cf bmd = INV ? make_float2(-t.y, t.x) : make_float2(t.y, -t.x);        // -+ j (x1 - x3)
+                const cf y0 = cadd(apc, bpd), y1 = cadd(amc, bmd), y2 = csub(apc, bpd), y3 = csub(amc, bmd);
+                const int e = pp * s;                             // W_n^{p j} = wK[p j s]
+                yout[0] = y0;
+                const cf w1 = wK[e], w2 = wK[2 * e], w3 = wK[3 * e];
+                yout[out_step] = INV ? cmulj(y1, w1) : cmul(y1, w1);
+                yout[2 * out_step] = INV ? cmulj(y2, w2) : cmul(y2, w2);
+                yout[3 * out_step] = INV ? cmulj(y3, w3) : cmul(y3, w3);
+            } else if (r == 2) {
+                const cf u = xin[0], v = xin[in_step];
+                const cf w = wK[pp * s], d = csub(u, v);
+                yout[0] = cadd(u, v);
+                yout[out_step] = INV ? cmulj(d, w) : cmul(d, w);
+            } else {
+                for (int j = 0; j < r; ++j) {
+                    cf acc = make_float2(0.f, 0.f);
+                    int e = 0;                                    // j k K / r  (mod K)
+                    for (int k = 0; k < r; ++k) {
+                        const cf w = wK[e];
+                        acc = INV ? cfmaj(xin[k * in_step], w, acc) : cfma(xin[k * in_step], w, acc);
+                        e += j * rstep;
+                        if (e >= K) e -= K;
+                    }
+                    const cf w = wK[(int)(((long long)pp * j * s) % K)];
+                    yout[j * out_step] = INV ? cmulj(acc, w) : cmul(acc, w);
+                }
             }
-            __syncthreads();
-            cf* t = x; x = y; y = t;
         }
-        return x;
+        __syncthreads();
+        cf* t = x; x = y; y = t;
+        n = m;
+        s *= r;
     }
-    for (int idx = threadIdx.x; idx < K * M; idx += GT) {
-        const int j = idx / M, m = idx - j * M;
-        cf acc = make_float2(0.f, 0.f);
-        int e = 0;
-        for (int q = 0; q < K; ++q) {
-            const cf w = wK[e];
-            acc = INV ? cfmaj(x[q * M + m], w, acc) : cfma(x[q * M + m], w, acc);
-            e += j;
-            if (e >= K) e -= K;
-        }
-        y[idx] = acc;
-    }
-    __syncthreads();
-    return y;
+    return x;
 }
 
 // estimate_preamble_channel :118-145 -- K-point FFT of both preamble halves, times 0.5 / FFT(known half), summed.
