@@ -131,7 +131,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     tables.insert(tables.end(), pl.h_taps.begin(), pl.h_taps.end());
     tables.insert(tables.end(), pl.h_ictaps.begin(), pl.h_ictaps.end());
     for (int m = 0; m < M; ++m) tables.push_back(make_float2(pl.h_ictaps[m].x / (float)M, pl.h_ictaps[m].y / (float)M));
-    // g = IDFT_M(ic)/M in double: one IC round is d_new = d0 - g (*) (dec_{k-1} + dec_{k+1})  (gfdm_rowlane.hip)
+    // g = IDFT_M(ic)/M in double: one IC round is d_new = d0 - g (*) (dec_{k-1} + dec_{k+1})  (gfdm_rowlane_impl.h)
     bool ic_real_sym = true;
     {
         const double two_pi = 6.283185307179586476925286766559;

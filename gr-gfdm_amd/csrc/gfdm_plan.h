@@ -79,7 +79,7 @@ hipError_t launch_fast_modulate(const DevicePlan& p, const cf* twT, cf* out, con
 hipError_t launch_fast_receive(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in, const cf* f_eq,
                                int64_t nblocks, hipStream_t s);
 
-// ---- row-lane family (gfdm_rowlane.hip): one lane per subcarrier row, LDS ping-pong radix-4 passes ----
+// ---- row-lane family (gfdm_rowlane_impl.h, dispatch in gfdm_rowlane.hip): one lane per subcarrier row, in-place radix-4 passes ----
 bool rowlane_supports(int M, int K, int L);
 hipError_t launch_rowlane_modulate(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks,
                                    hipStream_t s);
