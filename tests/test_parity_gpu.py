@@ -409,3 +409,29 @@ def test_device_entry_points_are_graph_capturable():
     assert rel_err(x.cpu().numpy(), ref_x) < TOL
     assert rel_err(y.cpu().numpy(), R.demodulate(ref_x, nt, M, K, L)) < TOL
     assert float((z - sym).abs().max()) < 0.2
+
+
+@pytest.mark.parametrize("M,K,L", [(3, 7, 2), (5, 13, 2), (4, 28, 3), (7, 30, 2), (3, 36, 4), (9, 50, 2), (5, 66, 2), (2, 99, 2), (11, 8, 2), (6, 40, 5),
+                                   (1, 16, 2), (3, 2, 2)])
+def test_generic_family_any_subcarrier_count(M, K, L):
+    """The generic family's subcarrier transform is a mixed-radix Stockham FFT (radices 4, 2, 3, 5, 7, 11, 13 here, a prime K as one
+    direct pass): modulator, ZF receiver and IC receiver against the float64 oracle on awkward shapes."""
+    import gfdm_amd
+    rng = np.random.default_rng(100 * K + 10 * M + L)
+    N, B = M * K, 5
+    taps = get_frequency_domain_filter("rrc", 0.4, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    assert mod.kernel_name() == "generic_lds"
+    sym = qpsk(rng, (B, N))
+    x = R.modulate(sym, nt, M, K, L)
+    assert rel_err(mod.modulate(sym), x) < TOL
+    feq = np.fft.fft(np.array([1, .3 - .2j, .1j]), N)[None, :] * np.ones((B, 1))
+    xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
+    assert rel_err(dem.demodulate_equalize(xe, feq), R.demodulate(xe, nt, M, K, L, feq)) < TOL
+    assert rel_err(dem.demodulate(x), R.demodulate(x, nt, M, K, L)) < TOL
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+    ref, st = R.advanced_receive(xe, nt, M, K, L, np.arange(K), R.qpsk_points(), 2, f_eq=feq, kind="qpsk", return_stages=True)
+    keep = guarded(st, np.arange(K), K, M)
+    if keep.any():
+        assert rel_err(adv.demodulate_equalize(xe, feq)[keep], ref[keep]) < TOL
