@@ -143,7 +143,7 @@ __device__ __forceinline__ void load_fft_twiddles(FftTwiddles<K>& t, int lane, c
     });
 }
 
-template <int K, int M, bool INV>
+template <int K, int M, bool INV, int FIRST = 0>
 __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const FftTwiddles<K>& twd)
 {
     using S = RowShape<K>;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
     const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
     const cf* rb[4];
     static_for<0, 4>([&](auto ri) { constexpr int r = decltype(ri)::value; rb[r] = tile + LY::slot(tq + RG * r) * M + c0; });
-    static_for<0, S::NP4>([&](auto si) {
+    static_for<FIRST, S::NP4>([&](auto si) {
         constexpr int s = decltype(si)::value;
         constexpr int str = pow4(s), len = K / str, ms = len / 4;
         constexpr bool last = (s == S::NP4 - 1) && !S::HAS2;      // the pass that leaves the data in natural order
@@ -202,6 +202,57 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
         });
         block_sync<K>();
     }
+}
+
+// ---- K = 64: the FIRST radix-4 pass straight from the lanes' registers ------------------------------------------------------
+// Before the subcarrier FFT lane q = 16 rr + tq holds row q (all columns); the first pass combines rows tq, tq + 16, tq + 32,
+// tq + 48, i.e. the SAME lane of the four 16-lane rows of the wavefront.  A 4 x 4 transpose between four registers and the four
+// lane rows (v_permlane32_swap + v_permlane16_swap, two of each per 32-bit component) hands lane (rr, tq) the four inputs of
+// the butterfly of column 4 c + rr: the pass needs neither the row store to the tile nor the 12 LDS reads nor the ordering
+// point between them, and all 64 lanes work (the LDS form leaves the lanes of the fourth column group idle).
+#ifndef GFDM_NO_REG_FIRST_PASS
+constexpr bool kRegFirstPass = true;
+#else
+constexpr bool kRegFirstPass = false;
+#endif
+
+// register i of lane row rr  <-  register rr of lane row i.  v_permlane32_swap(a, b): rows 2,3 of a <-> rows 0,1 of b;
+// v_permlane16_swap(a, b): rows 1,3 of a <-> rows 0,2 of b (checked on hardware, scratch/probe/permlane.hip).
+__device__ __forceinline__ void lane_row_transpose4(float& f0, float& f1, float& f2, float& f3)
+{
+    unsigned a0 = __builtin_bit_cast(unsigned, f0), a1 = __builtin_bit_cast(unsigned, f1);
+    unsigned a2 = __builtin_bit_cast(unsigned, f2), a3 = __builtin_bit_cast(unsigned, f3);
+    const auto r = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
+    const auto s = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
+    const auto t = __builtin_amdgcn_permlane16_swap(r[0], s[0], false, false);
+    const auto u = __builtin_amdgcn_permlane16_swap(r[1], s[1], false, false);
+    f0 = __builtin_bit_cast(float, (unsigned)t[0]);
+    f1 = __builtin_bit_cast(float, (unsigned)t[1]);
+    f2 = __builtin_bit_cast(float, (unsigned)u[0]);
+    f3 = __builtin_bit_cast(float, (unsigned)u[1]);
+}
+
+template <int M, bool INV>
+__device__ __forceinline__ void wave_fft_first_pass(cf* tile, int lane, const FftTwiddles<64>& twd, const cf (&row)[M])
+{
+    using LY = FftLayout<64>;
+    const int tq = lane & 15, rr = lane >> 4;
+    const cf w1 = twd.w[0][0], w2 = twd.w[0][1], w3 = twd.w[0][2];
+    cf* wb[4];
+    static_for<0, 4>([&](auto ui) { constexpr int u = decltype(ui)::value; wb[u] = tile + LY::slot(4 * tq + u) * M + rr; });
+    static_for<0, (M + 3) / 4>([&](auto gi) {
+        constexpr int c4 = 4 * decltype(gi)::value;
+        cf a[4];
+        static_for<0, 4>([&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (c4 + i < M) a[i] = row[c4 + i]; else a[i] = mk(0.f, 0.f); });
+        lane_row_transpose4(a[0].x, a[1].x, a[2].x, a[3].x);
+        lane_row_transpose4(a[0].y, a[1].y, a[2].y, a[3].y);
+        Dft<4, INV>::run(a);                                       // rows tq, tq + 16, tq + 32, tq + 48 of column c4 + rr
+        a[1] = cmul_dir<INV>(a[1], w1);
+        a[2] = cmul_dir<INV>(a[2], w2);
+        a[3] = cmul_dir<INV>(a[3], w3);
+        if (c4 + rr < M) { wb[0][c4] = a[0]; wb[1][c4] = a[1]; wb[2][c4] = a[2]; wb[3][c4] = a[3]; }
+    });
+    block_sync<64>();
 }
 
 // lane i <- lane (i -+ 1) mod 64: DPP wave rotates (GFX9 dpp_ctrl 0x13C = wave_ror:1, 0x134 = wave_rol:1)
@@ -290,13 +341,20 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     cf tw[M];
     static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; tw[m] = twT[m * K + q]; });
     dft_inplace<M, false>(v);
-    {
+    constexpr bool REGPASS = (K == 64) && kRegFirstPass;
+    if constexpr (REGPASS) {
+        cf rowv[MS];
+        rowv[0] = v[0];
+        static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; rowv[m] = cmul(v[m], tw[m]); });
+        if constexpr (EQ == EQ_PREAMBLE) { rowv[M] = pre0; rowv[M + 1] = pre1; }
+        wave_fft_first_pass<MS, false>(X, q, twd, rowv);
+    } else {
         cf* xa = X + FftLayout<K>::slot(q) * MS;                   // row q goes to its FFT slot
         xa[0] = v[0];
         static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = cmul(v[m], tw[m]); });
         if constexpr (EQ == EQ_PREAMBLE) { xa[M] = pre0; xa[M + 1] = pre1; }
+        block_sync<K>();
     }
-    block_sync<K>();
     // The equaliser vector is needed only after the subcarrier FFT: request it now, behind every wave's sample loads
     // (HBM serves requests roughly in issue order, so the samples of all waves arrive first and the transforms start
     // earlier; f_eq streams in while phases A/B run).
@@ -311,7 +369,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     }
 
     // ---- phase B: subcarrier FFT, in place
-    lds_subcarrier_fft<K, MS, false>(X, q, twd);
+    lds_subcarrier_fft<K, MS, false, REGPASS ? 1 : 0>(X, q, twd);
 
     GFDM_STAMP(2);
     // ---- phase C: X[f] / f_eq[f] in linear order (a conj(b) / |b|^2, reciprocal by v_rcp_f32)              rx:315-316
@@ -592,12 +650,16 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
         });
     }
     block_sync<K>();                                      // neighbour rows read by everyone before they are overwritten
-    {
+    constexpr bool REGPASS = (K == 64) && kRegFirstPass;
+    static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = scale(v[m], invN); });
+    if constexpr (REGPASS) {
+        wave_fft_first_pass<M, true>(X, q, twd, v);       // first pass of the inverse FFT from the registers
+    } else {
         cf* xa = X + FftLayout<K>::slot(q) * M;
-        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = scale(v[m], invN); });
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; xa[m] = v[m]; });
+        block_sync<K>();
     }
-    block_sync<K>();
-    lds_subcarrier_fft<K, M, true>(X, q, twd);                                                          // inverse over j
+    lds_subcarrier_fft<K, M, true, REGPASS ? 1 : 0>(X, q, twd);                                         // inverse over j
     v[0] = X[q * M];
     static_for<1, M>([&](auto mi) {
         constexpr int m = decltype(mi)::value;
@@ -695,11 +757,17 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_estimate(EstPlan est, c
     const cf inv0 = est.inv0[q], inv1 = est.inv1[q];
     FftTwiddles<K> twd;
     load_fft_twiddles<K>(twd, q, est.wK);
-    cf* xa = X + FftLayout<K>::slot(q) * 2;
-    xa[0] = p0;
-    xa[1] = p1;
-    block_sync<K>();
-    lds_subcarrier_fft<K, 2, false>(X, q, twd);                                    // both halves           est:118-145
+    constexpr bool REGPASS = (K == 64) && kRegFirstPass;
+    if constexpr (REGPASS) {
+        const cf halves[2] = { p0, p1 };
+        wave_fft_first_pass<2, false>(X, q, twd, halves);
+    } else {
+        cf* xa = X + FftLayout<K>::slot(q) * 2;
+        xa[0] = p0;
+        xa[1] = p1;
+        block_sync<K>();
+    }
+    lds_subcarrier_fft<K, 2, false, REGPASS ? 1 : 0>(X, q, twd);                   // both halves           est:118-145
     const cf eq = cfma(X[2 * q], inv0, cmul(X[2 * q + 1], inv1));
     const int pos = est_active_pos(q, est), n_est = est.n_est;
     if (pos >= 0) {                                                                //                       est:147-175
