@@ -22,6 +22,7 @@ Beside the headline the JSON line carries
 """
 import argparse
 import ctypes
+import ctypes.util
 import gc
 import json
 import os
@@ -179,7 +180,10 @@ def cpu_baseline(taps, batch_blocks, seconds):
     return {"value": multi, "unit": "blocks/s", "cores": T, "kind": "port",
             "sample": "mod + MF demod of %d QPSK blocks (K=64 M=9 L=2) in %.0f s on %d threads, one plain-C oracle kernel object "
                       "per thread (-O3 -march=native); single thread: %d blocks in %.0f s" % (nT, seconds, T, n1, seconds),
-            "single_thread_value": single, "cpu_model": model, "host_logical_cpus": os.cpu_count()}
+            "single_thread_value": single, "cpu_model": model, "host_logical_cpus": os.cpu_count(),
+            # the reference's own CPU kernels need FFTW3f and VOLK; neither is installed on the boxes of this pool (probe),
+            # so the only CPU figure is the plain-C restatement of the same per-block algorithm
+            "reference_libs_present": {"fftw3f": ctypes.util.find_library("fftw3f") is not None, "volk": ctypes.util.find_library("volk") is not None}}
 
 
 def main():
