@@ -68,6 +68,11 @@ public:
      * rx_preambles + b * preamble_stride, 0 = packed) instead of an equaliser vector; the block I/O follows configure_frames when
      * that was called, else plain blocks (noutput_size ignored).  The estimator object must outlive its use; nullptr detaches. --- */
     void set_channel_estimator(preamble_channel_estimator_cc* estimator);
+    /* sizes of one generic_work_frames_* (estimated = false) or generic_work_estimated_* (true) call with this noutput_size, in
+     * complex samples per frame / block -- asked from the library, which alone knows what its kernels write; throws where the call
+     * itself would (no configure_frames / estimator, noutput_size without a subcarrier map or above active * timeslots) */
+    struct io_layout_t { int n_in; int n_out; int est_fft_len; };
+    io_layout_t io_layout(bool estimated, int noutput_size) const;
     void generic_work_estimated_batch(gfdm_complex* out, const gfdm_complex* in, const gfdm_complex* rx_preambles, int preamble_stride, int noutput_size, long nblocks);
     void generic_work_estimated_device(void* d_out, const void* d_in, const void* d_rx_preambles, int preamble_stride, int noutput_size, long nblocks,
                                        void* hip_stream);

@@ -128,6 +128,13 @@ void advanced_receiver_kernel_cc::generic_work_estimated_device(void* d_out, con
           "advanced receiver generic_work_estimated_device");
 }
 
+advanced_receiver_kernel_cc::io_layout_t advanced_receiver_kernel_cc::io_layout(bool estimated, int noutput_size) const
+{
+    io_layout_t ly{ 0, 0, 0 };
+    raise(gfdm_hip_advanced_receiver_io_layout(d_handle, estimated ? 1 : 0, noutput_size, &ly.n_in, &ly.n_out, &ly.est_fft_len), "io_layout");
+    return ly;
+}
+
 const char* advanced_receiver_kernel_cc::kernel_name() const { return gfdm_hip_advanced_receiver_kernel_name(d_handle); }
 
 } // namespace gfdm

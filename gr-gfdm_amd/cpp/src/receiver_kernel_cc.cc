@@ -137,6 +137,13 @@ void receiver_kernel_cc::generic_work_estimated_device(void* d_out, const void* 
                    "receiver generic_work_estimated_device");
 }
 
+receiver_kernel_cc::io_layout_t receiver_kernel_cc::io_layout(bool estimated, int noutput_size) const
+{
+    io_layout_t ly{ 0, 0, 0 };
+    throw_on_error(gfdm_hip_receiver_io_layout(d_handle, estimated ? 1 : 0, noutput_size, &ly.n_in, &ly.n_out, &ly.est_fft_len), "io_layout");
+    return ly;
+}
+
 const char* receiver_kernel_cc::kernel_name() const { return gfdm_hip_receiver_kernel_name(d_handle); }
 
 // ---- legacy 2-D API: [subcarrier][timeslot] vectors <-> the flat subcarrier-major block ----

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <new>
@@ -41,6 +42,9 @@ int fail_hip(hipError_t e, const char* what)
         if (_e != hipSuccess) return fail_hip(_e, #expr);        \
     } while (0)
 
+// test hook (gfdm_hip_force_generic_family_for_testing): handles created while it is set use the generic kernel family
+std::atomic<int> g_force_generic{ 0 };
+
 struct Plan {
     int device = 0;
     gfdm::DevicePlan dp{};
@@ -50,7 +54,7 @@ struct Plan {
     cf* stage[3] = { nullptr, nullptr, nullptr };
     size_t stage_elems[3] = { 0, 0, 0 };
     std::string kernel_name;
-    const cf* d_twT = nullptr;       // [M][K] twiddles of the fast family
+    const cf* d_twT = nullptr;       // [M][K] twiddles W_N^{q m}, transposed so that lane q reads them coalesced (row-lane family)
     int family = gfdm::FAMILY_GENERIC;
 
     ~Plan()
@@ -184,15 +188,10 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     dp.wK = dp.wM + M;
     dp.wN = dp.wK + K;
     pl.d_twT = pl.d_tables + twT_off;
-    // kernel family: row-lane where instantiated, then the 4-rows-per-lane family, else the generic LDS family.
-    // GFDM_HIP_FAMILY=generic|fast|rowlane overrides the choice (experiments, A/B timing).
-    pl.family = gfdm::rowlane_supports(M, K, L) ? gfdm::FAMILY_ROWLANE : gfdm::fast_supports(M, K, L) ? gfdm::FAMILY_FAST : gfdm::FAMILY_GENERIC;
-    if (const char* want = getenv("GFDM_HIP_FAMILY")) {
-        if (!strcmp(want, "generic")) pl.family = gfdm::FAMILY_GENERIC;
-        else if (!strcmp(want, "fast") && gfdm::fast_supports(M, K, L)) pl.family = gfdm::FAMILY_FAST;
-        else if (!strcmp(want, "rowlane") && gfdm::rowlane_supports(M, K, L)) pl.family = gfdm::FAMILY_ROWLANE;
-    }
-    pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : pl.family == gfdm::FAMILY_FAST ? "fast_wave_tile" : "generic_lds";
+    // kernel family: row-lane where the shape is instantiated, else the generic LDS family.  Only the explicit test hook
+    // gfdm_hip_force_generic_family_for_testing changes that; no environment variable does.
+    pl.family = (gfdm::rowlane_supports(M, K, L) && !g_force_generic.load()) ? gfdm::FAMILY_ROWLANE : gfdm::FAMILY_GENERIC;
+    pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : "generic_lds";
     return GFDM_HIP_OK;
 }
 
@@ -255,15 +254,12 @@ hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, cons
                             hipStream_t s, const gfdm::EstPlan* est = nullptr)
 {
     if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
-    const bool plain_io = !ic.io.demap && !ic.io.in_offset && (ic.io.in_stride == 0 || ic.io.in_stride == pl.dp.N);
-    if (pl.family == gfdm::FAMILY_FAST && plain_io && !est) return gfdm::launch_fast_receive(pl.dp, ic, pl.d_twT, mode, out, in, f_eq, nblocks, s);
     return gfdm::launch_generic_receive(pl.dp, ic, est, mode, out, in, f_eq, nblocks, s);
 }
 
 hipError_t mod_launch(Plan& pl, const gfdm::TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
     if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_modulate(pl.dp, tx, pl.d_twT, out, in, nblocks, s);
-    if (pl.family == gfdm::FAMILY_FAST && !tx.mapped && !tx.framed) return gfdm::launch_fast_modulate(pl.dp, pl.d_twT, out, in, nblocks, s);
     return gfdm::launch_generic_modulate(pl.dp, tx, out, in, nblocks, s);
 }
 
@@ -324,6 +320,11 @@ int frame_io_for_call(const FrameIo& f, const Plan& pl, int noutput_size, gfdm::
             return fail(GFDM_HIP_EINVAL, buf);                     // resource_mapper_kernel_cc.cc:95-99
         }
         if (noutput_size > 0) io.nout = noutput_size;
+    } else if (noutput_size > 0 && noutput_size != io.nout) {
+        // no demapper in the store stage: the kernel writes the whole [k][m] block, a shorter caller buffer would be overrun
+        char buf[200];
+        snprintf(buf, sizeof(buf), "noutput_size(%d) needs a subcarrier map: without one every frame yields block_size(%d) symbols", noutput_size, io.nout);
+        return fail(GFDM_HIP_EINVAL, buf);
     }
     return GFDM_HIP_OK;
 }
@@ -364,6 +365,11 @@ const char* gfdm_hip_strerror(int status)
 }
 
 const char* gfdm_hip_last_error(void) { return g_last_error.c_str(); }
+
+int gfdm_hip_force_generic_family_for_testing(int enable)
+{
+    return g_force_generic.exchange(enable ? 1 : 0);
+}
 
 int gfdm_hip_device_count(void)
 {
@@ -1028,9 +1034,8 @@ int gfdm_hip_channel_estimator_create(gfdm_hip_channel_estimator** out, int time
     e.wK = e.inv1 + K;
     e.w2K = e.wK + K;
     // estimate_frame runs in the row-lane layout where a shape with this (fft_len, timeslots) is instantiated; the single stages,
-    // prepare_for_zf and estimate_snr always use the generic kernels.  GFDM_HIP_FAMILY=generic forces the generic estimate_frame.
-    const char* want = getenv("GFDM_HIP_FAMILY");
-    c->plan.family = (gfdm::rowlane_supports_estimate(timeslots, K) && !(want && !strcmp(want, "generic"))) ? gfdm::FAMILY_ROWLANE : gfdm::FAMILY_GENERIC;
+    // prepare_for_zf and estimate_snr always use the generic kernels.
+    c->plan.family = (gfdm::rowlane_supports_estimate(timeslots, K) && !g_force_generic.load()) ? gfdm::FAMILY_ROWLANE : gfdm::FAMILY_GENERIC;
     c->plan.kernel_name = c->plan.family == gfdm::FAMILY_ROWLANE ? "rowlane" : "generic_lds";
     *out = c.release();
     return GFDM_HIP_OK;
@@ -1181,6 +1186,7 @@ int est_call_io(const FrameIo& f, const Plan& pl, const gfdm_hip_channel_estimat
         int rc = frame_io_for_call(f, pl, noutput_size, io);
         if (rc != GFDM_HIP_OK) return rc;
     } else {
+        if (noutput_size > 0 && noutput_size != pl.dp.N) return fail(GFDM_HIP_EINVAL, "noutput_size needs configure_frames with a subcarrier map");
         io.in_stride = pl.dp.N;
         io.nout = pl.dp.N;
     }
@@ -1205,6 +1211,39 @@ int est_call_host(Plan& pl, const gfdm::RxIo& io, const gfdm::EstPlan& ep, float
 }  // namespace
 
 extern "C" {
+
+namespace {
+int io_layout(const FrameIo& f, const Plan& pl, const gfdm_hip_channel_estimator* c, int estimated, int noutput_size, int* n_in, int* n_out,
+              int* est_fft_len)
+{
+    gfdm::RxIo io{};
+    int rc;
+    if (estimated) {
+        gfdm::EstPlan ep;
+        rc = est_call_io(f, pl, c, 0, noutput_size, io, ep);
+    } else {
+        rc = frame_io_for_call(f, pl, noutput_size, io);
+    }
+    if (rc != GFDM_HIP_OK) return rc;
+    if (n_in) *n_in = io.in_stride;
+    if (n_out) *n_out = io.nout;
+    if (est_fft_len) *est_fft_len = c ? c->ep.K : 0;
+    return GFDM_HIP_OK;
+}
+}  // namespace
+
+int gfdm_hip_receiver_io_layout(const gfdm_hip_receiver* r, int estimated, int noutput_size, int* n_in, int* n_out, int* est_fft_len)
+{
+    if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    return io_layout(r->frames, r->plan, r->est, estimated, noutput_size, n_in, n_out, est_fft_len);
+}
+
+int gfdm_hip_advanced_receiver_io_layout(const gfdm_hip_advanced_receiver* a, int estimated, int noutput_size, int* n_in, int* n_out,
+                                         int* est_fft_len)
+{
+    if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
+    return io_layout(a->frames, a->plan, a->est, estimated, noutput_size, n_in, n_out, est_fft_len);
+}
 
 int gfdm_hip_receiver_set_channel_estimator(gfdm_hip_receiver* r, const gfdm_hip_channel_estimator* c)
 {

@@ -72,13 +72,6 @@ hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int6
 hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, const cf* fd, int64_t nblocks, hipStream_t s);
 bool generic_supports(int N, bool ic);
 
-// ---- fast family (gfdm_fast.hip): register/LDS tiles, one wavefront per workgroup, compile-time shapes ----
-// twT: [M][K] table, twT[m*K + q] = exp(-2 pi j q m / N)
-bool fast_supports(int M, int K, int L);
-hipError_t launch_fast_modulate(const DevicePlan& p, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
-hipError_t launch_fast_receive(const DevicePlan& p, const IcParams& ic, const cf* twT, int mode, cf* out, const cf* in, const cf* f_eq,
-                               int64_t nblocks, hipStream_t s);
-
 // ---- row-lane family (gfdm_rowlane_impl.h, dispatch in gfdm_rowlane.hip): one lane per subcarrier row, in-place radix-4 passes ----
 bool rowlane_supports(int M, int K, int L);
 hipError_t launch_rowlane_modulate(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks,
@@ -117,6 +110,6 @@ hipError_t launch_prepare_for_zf(cf* out, const cf* in, int64_t n, hipStream_t s
 bool rowlane_supports_estimate(int M, int K);
 hipError_t launch_rowlane_estimate(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s);   // rx preamble -> frame
 
-enum KernelFamily { FAMILY_GENERIC = 0, FAMILY_FAST = 1, FAMILY_ROWLANE = 2 };
+enum KernelFamily { FAMILY_GENERIC = 0, FAMILY_ROWLANE = 2 };
 
 }  // namespace gfdm

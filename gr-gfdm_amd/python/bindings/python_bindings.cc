@@ -13,7 +13,6 @@
 #include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm/transmitter_kernel.h>
 
-#include <unordered_map>
 
 namespace py = pybind11;
 using namespace gr::gfdm;
@@ -72,16 +71,17 @@ py::array_t<cfloat> rx_binary(receiver_kernel_cc& self, const carray& array, con
     return result;
 }
 
-// frames of frame_len samples in, (nframes, noutput) demapped symbols out
+// frames of frame_len samples in, (nframes, noutput) demapped symbols out.  Input stride and output size come from the library
+// (io_layout): it alone knows what the kernels write for this handle's configuration and this noutput_size.
 template <typename Kernel>
-py::array_t<cfloat> run_frames(Kernel& self, const carray& frames, py::object eq, int frame_len, int nout_all, int noutput_size)
+py::array_t<cfloat> run_frames(Kernel& self, const carray& frames, py::object eq, int noutput_size)
 {
+    const auto ly = self.io_layout(false, noutput_size);
     py::buffer_info in = frames.request();
-    if (frame_len <= 0 || in.size % frame_len)
-        throw std::runtime_error("frames size(" + std::to_string(in.size) + ") MUST be a multiple of frame_len(" + std::to_string(frame_len) + ")!");
-    const long nframes = in.size / frame_len;
-    const int nout = noutput_size > 0 ? noutput_size : nout_all;
-    py::array_t<cfloat> result(std::vector<py::ssize_t>{ nframes, nout });
+    if (ly.n_in <= 0 || in.size % ly.n_in)
+        throw std::runtime_error("frames size(" + std::to_string(in.size) + ") MUST be a multiple of frame_len(" + std::to_string(ly.n_in) + ")!");
+    const long nframes = in.size / ly.n_in;
+    py::array_t<cfloat> result(std::vector<py::ssize_t>{ nframes, ly.n_out });
     py::buffer_info out = result.request();
     if (eq.is_none()) {
         self.generic_work_frames_batch(ptr(out), cptr(in), nullptr, noutput_size, nframes);
@@ -97,27 +97,22 @@ py::array_t<cfloat> run_frames(Kernel& self, const carray& frames, py::object eq
 
 // blocks (or frames, when configure_frames was called) + received preambles in, symbols out: the estimator runs inside the kernel
 template <typename Kernel>
-py::array_t<cfloat> run_estimated(Kernel& self, const carray& x, const carray& pre, int n_in, int nout_all, int fft_len, int preamble_stride,
-                                  int noutput_size)
+py::array_t<cfloat> run_estimated(Kernel& self, const carray& x, const carray& pre, int preamble_stride, int noutput_size)
 {
+    const auto ly = self.io_layout(true, noutput_size);
     py::buffer_info in = x.request(), p = pre.request();
-    if (n_in <= 0 || in.size == 0 || in.size % n_in)
-        throw std::runtime_error("Input size(" + std::to_string(in.size) + ") MUST be a multiple of " + std::to_string(n_in) + "!");
-    const long nblocks = in.size / n_in;
-    const long stride = preamble_stride > 0 ? preamble_stride : 2 * fft_len;
-    if (p.size < (nblocks - 1) * stride + 2 * fft_len)
+    if (ly.n_in <= 0 || in.size == 0 || in.size % ly.n_in)
+        throw std::runtime_error("Input size(" + std::to_string(in.size) + ") MUST be a multiple of " + std::to_string(ly.n_in) + "!");
+    const long nblocks = in.size / ly.n_in;
+    const long stride = preamble_stride > 0 ? preamble_stride : 2 * ly.est_fft_len;
+    if (p.size < (nblocks - 1) * stride + 2 * ly.est_fft_len)
         throw std::runtime_error("rx_preamble size(" + std::to_string(p.size) + ") MUST be at least " +
-                                 std::to_string((nblocks - 1) * stride + 2 * fft_len) + "!");
-    const int nout = noutput_size > 0 ? noutput_size : nout_all;
-    py::array_t<cfloat> result(std::vector<py::ssize_t>{ nblocks, nout });
+                                 std::to_string((nblocks - 1) * stride + 2 * ly.est_fft_len) + "!");
+    py::array_t<cfloat> result(std::vector<py::ssize_t>{ nblocks, ly.n_out });
     py::buffer_info out = result.request();
     self.generic_work_estimated_batch(ptr(out), cptr(in), cptr(p), preamble_stride, noutput_size, nblocks);
     return result;
 }
-
-// per-object frame layout remembered on the Python side (frame_len, symbols per frame)
-struct FrameLayout { int frame_len = 0; int nout = 0; int fft_len = 0; };
-std::unordered_map<const void*, FrameLayout> g_layouts;
 
 } // namespace
 
@@ -183,27 +178,22 @@ PYBIND11_MODULE(gfdm_python, m)
         .def("configure_frames",
              [](receiver_kernel_cc& self, int frame_len, int cp_len, std::vector<int> smap, bool per_timeslot) {
                  self.configure_frames(frame_len, cp_len, smap, per_timeslot);
-                 g_layouts[&self] = FrameLayout{ frame_len, smap.empty() ? self.block_size() : static_cast<int>(smap.size()) * self.timeslots(), g_layouts[&self].fft_len };
              },
              py::arg("frame_len"), py::arg("cp_len"), py::arg("subcarrier_map") = std::vector<int>(), py::arg("per_timeslot") = true)
         .def("demodulate_frames",
              [](receiver_kernel_cc& self, const carray frames, py::object eq, int noutput_size) {
-                 const FrameLayout ly = g_layouts[&self];
-                 return run_frames(self, frames, eq, ly.frame_len, ly.nout, noutput_size);
+                 return run_frames(self, frames, eq, noutput_size);
              },
              py::arg("frames"), py::arg("f_eq") = py::none(), py::arg("noutput_size") = 0,
              "cyclic-prefix removal + demodulation + resource demapping of whole frames in one kernel launch")
         .def("set_channel_estimator",
              [](receiver_kernel_cc& self, preamble_channel_estimator_cc* est) {
                  self.set_channel_estimator(est);
-                 g_layouts[&self].fft_len = est ? est->fft_len() : 0;
              },
              py::arg("estimator").none(true), py::keep_alive<1, 2>())
         .def("demodulate_estimated",
              [](receiver_kernel_cc& self, const carray x, const carray rx_preamble, int preamble_stride, int noutput_size) {
-                 const FrameLayout ly = g_layouts[&self];
-                 return run_estimated(self, x, rx_preamble, ly.frame_len ? ly.frame_len : self.block_size(), ly.frame_len ? ly.nout : self.block_size(),
-                                      ly.fft_len, preamble_stride, ly.frame_len ? noutput_size : 0);
+                 return run_estimated(self, x, rx_preamble, preamble_stride, noutput_size);
              },
              py::arg("x"), py::arg("rx_preamble"), py::arg("preamble_stride") = 0, py::arg("noutput_size") = 0,
              "channel estimation from each block's received preamble + demodulation (+ prefix removal / demapping) in one kernel launch")
@@ -244,27 +234,23 @@ PYBIND11_MODULE(gfdm_python, m)
         .def("kernel_name", &advanced_receiver_kernel_cc::kernel_name)
         .def("configure_frames",
              [](advanced_receiver_kernel_cc& self, int frame_len, int cp_len, std::vector<int> smap, bool per_timeslot, int timeslots) {
+                 (void)timeslots;
                  self.configure_frames(frame_len, cp_len, smap, per_timeslot);
-                 g_layouts[&self] = FrameLayout{ frame_len, smap.empty() ? self.block_size() : static_cast<int>(smap.size()) * timeslots, g_layouts[&self].fft_len };
              },
              py::arg("frame_len"), py::arg("cp_len"), py::arg("subcarrier_map"), py::arg("per_timeslot"), py::arg("timeslots"))
         .def("demodulate_frames",
              [](advanced_receiver_kernel_cc& self, const carray frames, py::object eq, int noutput_size) {
-                 const FrameLayout ly = g_layouts[&self];
-                 return run_frames(self, frames, eq, ly.frame_len, ly.nout, noutput_size);
+                 return run_frames(self, frames, eq, noutput_size);
              },
              py::arg("frames"), py::arg("f_eq") = py::none(), py::arg("noutput_size") = 0)
         .def("set_channel_estimator",
              [](advanced_receiver_kernel_cc& self, preamble_channel_estimator_cc* est) {
                  self.set_channel_estimator(est);
-                 g_layouts[&self].fft_len = est ? est->fft_len() : 0;
              },
              py::arg("estimator").none(true), py::keep_alive<1, 2>())
         .def("demodulate_estimated",
              [](advanced_receiver_kernel_cc& self, const carray x, const carray rx_preamble, int preamble_stride, int noutput_size) {
-                 const FrameLayout ly = g_layouts[&self];
-                 return run_estimated(self, x, rx_preamble, ly.frame_len ? ly.frame_len : self.block_size(), ly.frame_len ? ly.nout : self.block_size(),
-                                      ly.fft_len, preamble_stride, ly.frame_len ? noutput_size : 0);
+                 return run_estimated(self, x, rx_preamble, preamble_stride, noutput_size);
              },
              py::arg("x"), py::arg("rx_preamble"), py::arg("preamble_stride") = 0, py::arg("noutput_size") = 0)
         .def("demodulate",

@@ -48,6 +48,7 @@ def lib():
         "gfdm_hip_strerror": (cp, [i32]),
         "gfdm_hip_last_error": (cp, []),
         "gfdm_hip_device_count": (i32, []),
+        "gfdm_hip_force_generic_family_for_testing": (i32, [i32]),
         "gfdm_hip_version": (cp, []),
         "gfdm_hip_modulator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
         "gfdm_hip_modulator_destroy": (i32, [vp]),
@@ -127,6 +128,8 @@ def lib():
         "gfdm_hip_channel_estimator_estimate_snr_device": (i32, [vp, vp, vp, vp, i64, vp]),
         "gfdm_hip_receiver_set_channel_estimator": (i32, [vp, vp]),
         "gfdm_hip_advanced_receiver_set_channel_estimator": (i32, [vp, vp]),
+        "gfdm_hip_receiver_io_layout": (i32, [vp, i32, i32, vp, vp, vp]),
+        "gfdm_hip_advanced_receiver_io_layout": (i32, [vp, i32, i32, vp, vp, vp]),
         "gfdm_hip_receiver_demodulate_estimated_host": (i32, [vp, vp, vp, vp, i32, i32, i64]),
         "gfdm_hip_receiver_demodulate_estimated_device": (i32, [vp, vp, vp, vp, i32, i32, i64, vp]),
         "gfdm_hip_advanced_receiver_work_estimated_host": (i32, [vp, vp, vp, vp, i32, i32, i64]),
@@ -163,22 +166,37 @@ def _is_tensor(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
 
 
-def _dev_ptr(t, n_elems, what):
+def _dev_ptr(t, n_elems, what, device=None):
     import torch
     if not t.is_cuda or t.dtype != torch.complex64 or not t.is_contiguous():
         raise TypeError("%s must be a contiguous complex64 CUDA/HIP tensor" % what)
+    if device is not None and t.device.index != device:
+        raise RuntimeError("%s lives on GPU %d, the kernel handle on GPU %d" % (what, t.device.index, device))
     if t.numel() != n_elems:
         raise RuntimeError("%s has %d elements, expected %d" % (what, t.numel(), n_elems))
     return t.data_ptr()
 
 
-def _stream_ptr(stream):
+def _stream_ptr(stream, device=None):
     if stream is None:
         import torch
-        return torch.cuda.current_stream().cuda_stream
+        return torch.cuda.current_stream(device).cuda_stream      # the current stream of the HANDLE's GPU, not of torch's current one
     if hasattr(stream, "cuda_stream"):
         return stream.cuda_stream
     return int(stream)
+
+
+class generic_family_for_testing:
+    """TEST HOOK: `with generic_family_for_testing(): h = Demodulator(...)` creates h on the generic kernel family even where the
+    tuned row-lane family serves the shape (gfdm_hip_force_generic_family_for_testing); used by tests/ to run both families."""
+
+    def __enter__(self):
+        self._prev = lib().gfdm_hip_force_generic_family_for_testing(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().gfdm_hip_force_generic_family_for_testing(self._prev)
+        return False
 
 
 class _Kernel:
@@ -186,6 +204,21 @@ class _Kernel:
     _destroy = None
     _frames_prefix = None          # C-ABI name stem of the *_frames_* entry points (receivers only)
     _configure_frames = None
+    _io_layout = None
+    _dev = 0                       # GPU the handle was created on: every tensor and the stream of a call must belong to it
+
+    def _dp(self, t, n_elems, what):
+        return _dev_ptr(t, n_elems, what, self._dev)
+
+    def _sp(self, stream):
+        return _stream_ptr(stream, self._dev)
+
+    def _layout(self, estimated, nout_arg):
+        """(n_in, n_out, estimator fft_len) of one frames / estimated call, asked from the library (gfdm_hip_*_io_layout): it alone
+        knows what its kernels write for this configuration, so no output buffer is ever sized from Python-side bookkeeping."""
+        n_in, n_out, fft_len = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _check(getattr(lib(), self._io_layout)(self._h, int(estimated), int(nout_arg), ctypes.byref(n_in), ctypes.byref(n_out), ctypes.byref(fft_len)))
+        return n_in.value, n_out.value, fft_len.value
 
     # ---- raw frames in, demapped symbols out (SURVEY.md section 8f row 2) ----
     def configure_frames(self, frame_len, cp_len, subcarrier_map=None, per_timeslot=True):
@@ -194,27 +227,27 @@ class _Kernel:
         smap = np.ascontiguousarray([] if subcarrier_map is None else subcarrier_map, dtype=np.int32)
         fn = getattr(lib(), self._configure_frames)
         _check(fn(self._h, int(frame_len), int(cp_len), smap.ctypes.data if smap.size else None, smap.size, int(bool(per_timeslot))))
-        self._frame_len = int(frame_len)
-        self._frame_nout = smap.size * (self.block_size() // self._frame_k) if smap.size else self.block_size()
 
     def demodulate_frames(self, frames, f_eq=None, noutput_size=None, out=None, stream=None):
         """frames: nframes * frame_len samples; returns (nframes, noutput_size) symbols (all active symbols by default)."""
         L = lib()
         nout_arg = -1 if noutput_size is None else int(noutput_size)
-        nout = self._frame_nout if noutput_size is None else int(noutput_size)
+        frame_len, nout, _ = self._layout(False, nout_arg)
         N = self.block_size()
         if _is_tensor(frames):
             import torch
-            nb = frames.numel() // self._frame_len
+            if frames.numel() % frame_len:
+                raise RuntimeError("frames size(%d) MUST be a multiple of frame_len(%d)!" % (frames.numel(), frame_len))
+            nb = frames.numel() // frame_len
             out = torch.empty(nb, nout, dtype=torch.complex64, device=frames.device) if out is None else out
-            feq = None if f_eq is None else _dev_ptr(f_eq, nb * N, "f_eq")
-            _check(getattr(L, self._frames_prefix + "_device")(self._h, _dev_ptr(out, nb * nout, "out"), _dev_ptr(frames, nb * self._frame_len, "frames"),
-                                                              feq, nout_arg, nb, _stream_ptr(stream)))
+            feq = None if f_eq is None else self._dp(f_eq, nb * N, "f_eq")
+            _check(getattr(L, self._frames_prefix + "_device")(self._h, self._dp(out, nb * nout, "out"), self._dp(frames, nb * frame_len, "frames"),
+                                                              feq, nout_arg, nb, self._sp(stream)))
             return out
         x = _c64(frames)
-        if x.size % self._frame_len:
-            raise RuntimeError("frames size(%d) MUST be a multiple of frame_len(%d)!" % (x.size, self._frame_len))
-        nb = x.size // self._frame_len
+        if x.size % frame_len:
+            raise RuntimeError("frames size(%d) MUST be a multiple of frame_len(%d)!" % (x.size, frame_len))
+        nb = x.size // frame_len
         e = None if f_eq is None else _c64(f_eq)
         if e is not None and e.size != nb * N:
             raise RuntimeError("Channel vector size(%d) MUST be equal to nframes * block_size(%d)!" % (e.size, nb * N))
@@ -234,27 +267,28 @@ class _Kernel:
         L = lib()
         if getattr(self, "_estimator", None) is None:
             raise ValueError("set_channel_estimator has not been called on this handle")
-        framed = getattr(self, "_frame_len", None) is not None
-        n_in = self._frame_len if framed else self.block_size()
         nout_arg = -1 if noutput_size is None else int(noutput_size)
-        nout = (self._frame_nout if noutput_size is None else int(noutput_size)) if framed else self.block_size()
-        stride = int(preamble_stride) if preamble_stride else 2 * self._estimator.fft_len()
+        n_in, nout, fft_len = self._layout(True, nout_arg)
+        stride = int(preamble_stride) if preamble_stride else 2 * fft_len
         if _is_tensor(x):
             import torch
+            if x.numel() % n_in:
+                raise RuntimeError("Input size(%d) MUST be a multiple of %d!" % (x.numel(), n_in))
             nb = x.numel() // n_in
             out = torch.empty(nb, nout, dtype=torch.complex64, device=x.device) if out is None else out
-            need = (nb - 1) * stride + 2 * self._estimator.fft_len() if nb else 0
-            if not rx_preamble.is_cuda or rx_preamble.dtype != torch.complex64 or not rx_preamble.is_contiguous() or rx_preamble.numel() < need:
-                raise TypeError("rx_preamble must be a contiguous complex64 CUDA/HIP tensor of at least %d elements" % need)
-            _check(getattr(L, self._estimated_prefix + "_device")(self._h, _dev_ptr(out, nb * nout, "out"), _dev_ptr(x, nb * n_in, "in"),
-                                                                 rx_preamble.data_ptr(), int(preamble_stride), nout_arg, nb, _stream_ptr(stream)))
+            need = (nb - 1) * stride + 2 * fft_len if nb else 0
+            if rx_preamble.numel() < need:
+                raise RuntimeError("rx_preamble has %d elements, at least %d are needed" % (rx_preamble.numel(), need))
+            self._dp(rx_preamble, rx_preamble.numel(), "rx_preamble")
+            _check(getattr(L, self._estimated_prefix + "_device")(self._h, self._dp(out, nb * nout, "out"), self._dp(x, nb * n_in, "in"),
+                                                                 rx_preamble.data_ptr(), int(preamble_stride), nout_arg, nb, self._sp(stream)))
             return out
         a = _c64(x)
         if a.size % n_in:
             raise RuntimeError("Input size(%d) MUST be a multiple of %d!" % (a.size, n_in))
         nb = a.size // n_in
         pre = _c64(rx_preamble)
-        need = (nb - 1) * stride + 2 * self._estimator.fft_len() if nb else 0
+        need = (nb - 1) * stride + 2 * fft_len if nb else 0
         if pre.size < need:
             raise RuntimeError("rx_preamble size(%d) MUST be at least %d!" % (pre.size, need))
         res = np.empty((nb, nout), np.complex64)
@@ -296,8 +330,8 @@ class _Kernel:
     def _device(self, fn, out, x, extra=(), stream=None):
         n = x.numel()
         nb = self._nblocks(n)
-        ptrs = [None if e is None else _dev_ptr(e, n, "extra input") for e in extra]
-        _check(fn(self._h, _dev_ptr(out, n, "out"), _dev_ptr(x, n, "in"), *ptrs, nb, _stream_ptr(stream)))
+        ptrs = [None if e is None else self._dp(e, n, "extra input") for e in extra]
+        _check(fn(self._h, self._dp(out, n, "out"), self._dp(x, n, "in"), *ptrs, nb, self._sp(stream)))
         return out
 
 
@@ -316,6 +350,7 @@ class Modulator(_Kernel):
         h = ctypes.c_void_p()
         _check(L.gfdm_hip_modulator_create(ctypes.byref(h), timeslots, subcarriers, overlap, tp, tn, device))
         self._h = h
+        self._dev = int(device)
         self._n = timeslots * subcarriers
         self._ntaps = tn
 
@@ -344,6 +379,7 @@ class Demodulator(_Kernel):
     _destroy = "gfdm_hip_receiver_destroy"
     _frames_prefix = "gfdm_hip_receiver_demodulate_frames"
     _configure_frames = "gfdm_hip_receiver_configure_frames"
+    _io_layout = "gfdm_hip_receiver_io_layout"
     _estimated_prefix = "gfdm_hip_receiver_demodulate_estimated"
     _set_estimator = "gfdm_hip_receiver_set_channel_estimator"
 
@@ -353,8 +389,8 @@ class Demodulator(_Kernel):
         h = ctypes.c_void_p()
         _check(L.gfdm_hip_receiver_create(ctypes.byref(h), timeslots, subcarriers, overlap, tp, tn, device))
         self._h = h
+        self._dev = int(device)
         self._M, self._K, self._L = timeslots, subcarriers, overlap
-        self._frame_k = subcarriers
 
     def timeslots(self):
         return lib().gfdm_hip_receiver_timeslots(self._h)
@@ -416,6 +452,7 @@ class AdvancedReceiver(_Kernel):
     _destroy = "gfdm_hip_advanced_receiver_destroy"
     _frames_prefix = "gfdm_hip_advanced_receiver_work_frames"
     _configure_frames = "gfdm_hip_advanced_receiver_configure_frames"
+    _io_layout = "gfdm_hip_advanced_receiver_io_layout"
     _estimated_prefix = "gfdm_hip_advanced_receiver_work_estimated"
     _set_estimator = "gfdm_hip_advanced_receiver_set_channel_estimator"
 
@@ -430,8 +467,8 @@ class AdvancedReceiver(_Kernel):
                                                    smap.ctypes.data, smap.size, ic_iter, pts.ctypes.data, pts.size,
                                                    DECIDE[decision], do_phase_compensation, device))
         self._h = h
+        self._dev = int(device)
         self._n = timeslots * subcarriers
-        self._frame_k = subcarriers
 
     def block_size(self):
         return self._n
@@ -491,6 +528,7 @@ class Transmitter(_Kernel):
                                              smap.ctypes.data, smap.size, int(bool(per_timeslot)), overlap, tp, tn, w.ctypes.data, w.size,
                                              shifts.ctypes.data, shifts.size, pre.ctypes.data, pre.shape[1] if pre.size else 0, device))
         self._h = h
+        self._dev = int(device)
         self._shifts = [int(x) for x in shifts]
 
     def input_vector_size(self):
@@ -525,7 +563,7 @@ class Transmitter(_Kernel):
             import torch
             outs = [torch.empty(nb, F, dtype=torch.complex64, device=symbols.device) for _ in range(ports)]
             arr = (ctypes.c_void_p * ports)(*[o.data_ptr() for o in outs])
-            _check(L.gfdm_hip_transmitter_work_device(self._h, arr, ports, _dev_ptr(symbols, nb * n, "in"), n, nb, _stream_ptr(stream)))
+            _check(L.gfdm_hip_transmitter_work_device(self._h, arr, ports, self._dp(symbols, nb * n, "in"), n, nb, self._sp(stream)))
             return outs
         x = _c64(symbols)
         outs = [np.empty((nb, F), np.complex64) for _ in range(ports)]
@@ -544,7 +582,7 @@ class Transmitter(_Kernel):
         if _is_tensor(symbols):
             import torch
             out = torch.empty(nb, N, dtype=torch.complex64, device=symbols.device)
-            _check(L.gfdm_hip_transmitter_modulate_device(self._h, out.data_ptr(), _dev_ptr(symbols, nb * n, "in"), n, nb, _stream_ptr(stream)))
+            _check(L.gfdm_hip_transmitter_modulate_device(self._h, out.data_ptr(), self._dp(symbols, nb * n, "in"), n, nb, self._sp(stream)))
             return out
         x = _c64(symbols)
         out = np.empty((nb, N), np.complex64)
@@ -558,7 +596,7 @@ class Transmitter(_Kernel):
             import torch
             nb = blocks.numel() // N
             out = torch.empty(nb, F, dtype=torch.complex64, device=blocks.device)
-            _check(L.gfdm_hip_transmitter_add_frame_device(self._h, out.data_ptr(), _dev_ptr(blocks, nb * N, "in"), int(cyclic_shift), nb, _stream_ptr(stream)))
+            _check(L.gfdm_hip_transmitter_add_frame_device(self._h, out.data_ptr(), self._dp(blocks, nb * N, "in"), int(cyclic_shift), nb, self._sp(stream)))
             return out
         x = _c64(blocks)
         nb = x.size // N
@@ -581,6 +619,7 @@ class ChannelEstimator(_Kernel):
         _check(L.gfdm_hip_channel_estimator_create(ctypes.byref(h), timeslots, fft_len, active_subcarriers, int(bool(is_dc_free)),
                                                    int(which_estimator), p.ctypes.data, p.size, device))
         self._h = h
+        self._dev = int(device)
 
     def timeslots(self):
         return lib().gfdm_hip_channel_estimator_timeslots(self._h)
@@ -621,7 +660,7 @@ class ChannelEstimator(_Kernel):
                 raise RuntimeError("Input size %d is not a multiple of %d" % (x.numel(), n_in))
             nf = x.numel() // n_in
             out = torch.empty((nf, n_out) if x.dim() > 1 or nf != 1 else (n_out,), dtype=torch.complex64, device=x.device)
-            _check(getattr(L, name + "_device")(self._h, out.data_ptr(), _dev_ptr(x, nf * n_in, "in"), nf, _stream_ptr(stream)))
+            _check(getattr(L, name + "_device")(self._h, out.data_ptr(), self._dp(x, nf * n_in, "in"), nf, self._sp(stream)))
             return out
         a = _c64(x)
         if a.size % n_in:
@@ -660,8 +699,8 @@ class ChannelEstimator(_Kernel):
             nf = rx_preamble.numel() // n_in
             snr = torch.empty(nf, dtype=torch.float32, device=rx_preamble.device)
             cnrs = torch.empty(nf, A, dtype=torch.float32, device=rx_preamble.device)
-            _check(L.gfdm_hip_channel_estimator_estimate_snr_device(self._h, snr.data_ptr(), cnrs.data_ptr(), _dev_ptr(rx_preamble, nf * n_in, "in"),
-                                                                    nf, _stream_ptr(stream)))
+            _check(L.gfdm_hip_channel_estimator_estimate_snr_device(self._h, snr.data_ptr(), cnrs.data_ptr(), self._dp(rx_preamble, nf * n_in, "in"),
+                                                                    nf, self._sp(stream)))
             return snr, cnrs
         a = _c64(rx_preamble)
         if a.size % n_in:

@@ -61,6 +61,10 @@ typedef struct gfdm_hip_advanced_receiver gfdm_hip_advanced_receiver;
 const char* gfdm_hip_strerror(int status);
 const char* gfdm_hip_last_error(void);
 int gfdm_hip_device_count(void);
+/* TEST HOOK, not part of the drop-in surface: handles created while `enable` is non-zero use the generic kernel family even
+ * for shapes the tuned row-lane family serves, so that the tests can run both families on the same shape.  Returns the previous
+ * setting.  Nothing else (no environment variable) changes the kernel family of a handle. */
+int gfdm_hip_force_generic_family_for_testing(int enable);
 const char* gfdm_hip_version(void);
 
 /* ---- modulator_kernel_cc (include/gfdm/modulator_kernel_cc.h:41-51) -------------------- */
@@ -233,7 +237,15 @@ int gfdm_hip_channel_estimator_estimate_snr_device(gfdm_hip_channel_estimator* c
  * rx_preamble: preamble of block b at rx_preamble + b * preamble_stride complex (0 = packed, 2 * fft_len) -- a burst buffer
  *   holding preamble and frame back to back is passed as `in` and, offset to the core preamble, as `rx_preamble`.
  * The block I/O follows configure_frames when that was called (frames in, demapped symbols out, noutput_size as there),
- * else plain blocks in and out (noutput_size ignored). */
+ * else plain blocks in and out (noutput_size must then be <= 0 or block_size). */
+/* Buffer sizes of ONE *_frames_* (estimated == 0) or *_estimated_* (estimated != 0) call with this noutput_size, in complex samples
+ * per frame / block: n_in read from `in`, n_out written to `out`, and the attached estimator's fft_len (0 = none).  The library is
+ * the authority on these sizes (a caller that derives them itself can under-allocate `out`): EINVAL where the call itself would
+ * fail -- no configure_frames / estimator, noutput_size above active_subcarriers * timeslots
+ * (lib/resource_mapper_kernel_cc.cc:95-99), or noutput_size given without a subcarrier map (the block is written whole). */
+int gfdm_hip_receiver_io_layout(const gfdm_hip_receiver* r, int estimated, int noutput_size, int* n_in, int* n_out, int* est_fft_len);
+int gfdm_hip_advanced_receiver_io_layout(const gfdm_hip_advanced_receiver* a, int estimated, int noutput_size, int* n_in, int* n_out,
+                                         int* est_fft_len);
 int gfdm_hip_receiver_set_channel_estimator(gfdm_hip_receiver* r, const gfdm_hip_channel_estimator* c);
 int gfdm_hip_advanced_receiver_set_channel_estimator(gfdm_hip_advanced_receiver* a, const gfdm_hip_channel_estimator* c);
 int gfdm_hip_receiver_demodulate_estimated_host(gfdm_hip_receiver* r, float* out, const float* in, const float* rx_preamble, int preamble_stride,

@@ -26,7 +26,21 @@ def pytest_configure(config):
 def golden_names():
     """kernel-path fixtures (make_golden.py); the composite-transmitter fixtures (make_golden_tx.py) are tx_*"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("tx_", "est_"))]
+    return [n for n in names if not n.startswith(("tx_", "est_", "ic_"))]
+
+
+def ic_golden_names():
+    """interference-cancellation fixtures (make_golden_ic.py): pygfdm's gfdm_get_ic_f_taps / gfdm_remove_sc_interference and
+    the composed decide -> cancel -> to_td loop"""
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "ic_*.npz")))
+
+
+def load_ic_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    for k in ("M", "K", "L", "seed"):
+        g[k] = int(g[k])
+    return g
 
 
 def est_golden_names():

@@ -75,7 +75,7 @@ def test_estimator_stages_against_oracle(M, K, A, dc_free):
         assert rel_err(fused[:, written], ref_i[:, written]) < TOL
 
 
-def test_estimate_frame_families_agree(monkeypatch):
+def test_estimate_frame_families_agree():
     """row-lane estimate_frame == generic estimate_frame (same device functions, different FFT) on a big ragged batch."""
     import gfdm_amd
     rng = np.random.default_rng(9)
@@ -83,9 +83,8 @@ def test_estimate_frame_families_agree(monkeypatch):
         pre = (rng.standard_normal(2 * K) + 1j * rng.standard_normal(2 * K)) / np.sqrt(2)
         rx = rng.standard_normal((1031, 2 * K)) + 1j * rng.standard_normal((1031, 2 * K))
         fast = gfdm_amd.ChannelEstimator(M, K, A, dc_free, 1, pre)
-        monkeypatch.setenv("GFDM_HIP_FAMILY", "generic")
-        slow = gfdm_amd.ChannelEstimator(M, K, A, dc_free, 1, pre)
-        monkeypatch.delenv("GFDM_HIP_FAMILY")
+        with gfdm_amd.generic_family_for_testing():
+            slow = gfdm_amd.ChannelEstimator(M, K, A, dc_free, 1, pre)
         assert (fast.kernel_name(), slow.kernel_name()) == ("rowlane", "generic_lds")
         a, b = fast.estimate_frame(rx), slow.estimate_frame(rx)
         assert rel_err(a, b) < 1e-5

@@ -73,12 +73,22 @@ def test_frames_against_oracle(M, K, L, alpha, per_ts):
     ref_adv, st = R.advanced_receive(x, nt, M, K, L, smap, R.qpsk_points(), 2, f_eq=feq, kind="qpsk", return_stages=True)
     ref_adv = R.demap_from_resources(ref_adv, M, K, smap, per_ts)
     assert rel_err(dem.demodulate_frames(frames, feq), ref_dem) < TOL
-    assert rel_err(adv.demodulate_frames(frames, feq), ref_adv) < TOL
+    # IC outputs only on blocks whose every decided component keeps DECISION_GUARD away from the boundary (tests/test_parity_gpu.py)
+    keep = np.ones(B, bool)
+    for dd in [st["d0"]] + st["iters"][:-1]:
+        v = dd.reshape(-1, K, M)[:, smap, :]
+        keep &= np.minimum(np.abs(v.real), np.abs(v.imag)).reshape(B, -1).min(axis=1) > 1e-4
+    assert keep.sum() >= B - 1
+    assert rel_err(adv.demodulate_frames(frames, feq)[keep], ref_adv[keep]) < TOL
     nshort = len(smap) * M - 5                                   # truncated output (noutput_size < active * timeslots)
     assert rel_err(dem.demodulate_frames(frames, feq, noutput_size=nshort), ref_dem[:, :nshort]) < TOL
     # no subcarrier map: prefix removal only, plain [k][m] blocks out
     dem.configure_frames(frame_len, cp)
     assert rel_err(dem.demodulate_frames(frames, feq), R.demodulate(x, nt, M, K, L, feq)) < TOL
+    # ... and without a map the kernel writes whole blocks: a truncating noutput_size is refused, never a short buffer overrun
+    with pytest.raises(gfdm_amd.GfdmHipError, match="needs a subcarrier map"):
+        dem.demodulate_frames(frames, feq, noutput_size=N - 7)
+    assert dem.demodulate_frames(frames, feq, noutput_size=N).shape == (B, N)
 
 
 def test_frames_device_path_and_errors():

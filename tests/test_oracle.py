@@ -89,6 +89,36 @@ def test_receiver_is_transpose_of_modulator(name):
     assert abs(lhs - rhs) / abs(lhs) < 1e-11
 
 
+def test_ic_stage_oracles_match_pygfdm():
+    """The IC stage pinned by the reference's Python model (tests/golden/make_golden_ic.py): gfdm_get_ic_f_taps ==
+    ic_filter_taps, gfdm_remove_sc_interference == cancel_sc_interference (real RRC taps and complex asymmetric taps), and
+    the composed loop to_td -> 5 x (QPSK decision, cancel against the UNCHANGED S, to_td) == advanced_receiver's IC rounds
+    (python/pygfdm/gfdm_receiver.py:91-114, utils.py:80-82)."""
+    from conftest import ic_golden_names, load_ic_golden
+    assert len(ic_golden_names()) >= 8
+    for name in ic_golden_names():
+        g = load_ic_golden(name)
+        M, K, L = g["M"], g["K"], g["L"]
+        allk = np.arange(K)
+        for taps, ic_ref, cancel_ref in ((g["taps"], g["pygfdm_ic_taps"], g["pygfdm_cancel"]),
+                                         (g["ctaps"], g["pygfdm_ic_ctaps"], g["pygfdm_cancel_ctaps"])):
+            nt = R.normalize_taps(taps, M)
+            o = c_oracle.COracle(M, K, L, taps)
+            assert rel_err(R.ic_filter_taps(nt, M, L), ic_ref) < TOL_F64
+            assert rel_err(o.ic_filter_taps(), ic_ref) < 1e-6
+            assert rel_err(R.cancel_sc_interference(g["td_in"], g["fd_in"], R.ic_filter_taps(nt, M, L), M, K), cancel_ref) < TOL_F64
+            assert rel_err(o.cancel_sc_interference(g["td_in"], g["fd_in"]), cancel_ref) < TOL_F32
+        nt = R.normalize_taps(g["taps"], M)
+        o = c_oracle.COracle(M, K, L, g["taps"])
+        assert rel_err(R.fft_filter_downsample(g["frames"], nt, M, K, L), g["S"]) < TOL_F64
+        assert rel_err(R.transform_subcarriers_to_td(g["S"], M, K), g["pygfdm_d0"]) < TOL_F64
+        rounds = g["pygfdm_ic_iters"]
+        for n in range(1, rounds.shape[0] + 1):
+            assert rel_err(R.advanced_receive(g["frames"], nt, M, K, L, allk, R.qpsk_points(), n, kind="qpsk"), rounds[n - 1]) < 1e-11
+            assert rel_err(o.advanced_receive(g["frames"], allk, R.qpsk_points(), n, kind="qpsk"), rounds[n - 1]) < TOL_F32
+            assert rel_err(o.advanced_receive(g["frames"], allk, R.qpsk_points(), n, kind="nearest"), rounds[n - 1]) < TOL_F32
+
+
 def test_ic_genie_known_answer():
     """qa_python_bindings.py:388-415: after two genie cancellations the demodulated symbols equal the data to 1 place."""
     g = load_golden("ref_m5_k32_a35")

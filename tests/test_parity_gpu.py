@@ -11,7 +11,7 @@ import pytest
 
 import c_oracle
 import gfdm_ref as R
-from conftest import assert_places, golden_names, have_gpu, load_golden, rel_err
+from conftest import assert_places, golden_names, have_gpu, ic_golden_names, load_golden, load_ic_golden, rel_err
 from gfdm_amd.filters import get_frequency_domain_filter
 
 pytestmark = pytest.mark.gpu
@@ -76,6 +76,42 @@ def test_golden_demodulator(name):
     got = dem.demodulate_equalize(g["frame_through_channel"][0], g["f_eq"][0])
     assert rel_err(got, g["pygfdm_demodulate"][0]) < TOL
     assert rel_err(dem.demodulate_batch(g["frame_through_channel"], g["f_eq"]), g["pygfdm_demodulate"]) < TOL
+
+
+@pytest.mark.parametrize("name", ic_golden_names())
+def test_golden_ic_stage(name):
+    """The IC stage against the reference's Python model (tests/golden/make_golden_ic.py; python/pygfdm/gfdm_receiver.py:99-114):
+    ic_filter_taps, cancel_sc_interference (real RRC taps -> real-symmetric kernel; complex taps -> general kernel), and the
+    receiver + IC rounds 1..5 with MF input (advanced_receiver_kernel_cc::generic_work) and ZF input (generic_work_equalize)."""
+    import gfdm_amd
+    import gfdm_python
+    g = load_ic_golden(name)
+    M, K, L = g["M"], g["K"], g["L"]
+    N = M * K
+    for taps, ic_ref, cancel_ref in ((g["taps"], g["pygfdm_ic_taps"], g["pygfdm_cancel"]),
+                                     (g["ctaps"], g["pygfdm_ic_ctaps"], g["pygfdm_cancel_ctaps"])):
+        dem = gfdm_python.Demodulator(M, K, L, taps)
+        hd = gfdm_amd.Demodulator(M, K, L, taps)
+        assert rel_err(np.array(hd.ic_filter_taps()), ic_ref) < 1e-6
+        for b in range(g["td_in"].shape[0]):
+            assert rel_err(dem.cancel_sc_interference(g["td_in"][b], g["fd_in"][b]), cancel_ref[b]) < TOL
+        assert rel_err(hd.cancel_sc_interference(g["td_in"], g["fd_in"]), cancel_ref) < TOL
+    hd = gfdm_amd.Demodulator(M, K, L, g["taps"])
+    assert rel_err(hd.fft_filter_downsample(g["frames"]), g["S"]) < TOL
+    assert rel_err(hd.transform_subcarriers_to_td(g["S"]), g["pygfdm_d0"]) < TOL
+    B = g["frames"].shape[0]
+    feq = np.fft.fft(np.array([1, .5, .1j, .1 + .05j]), N)[None, :] * np.exp(0.01j * np.arange(B))[:, None]
+    frames_ch = np.fft.ifft(np.fft.fft(g["frames"], axis=-1) * feq, axis=-1)
+    rounds = g["pygfdm_ic_iters"]
+    qp = gfdm_python.Constellation.qpsk()
+    for n in range(1, rounds.shape[0] + 1):
+        for decision in ("auto", "nearest"):
+            adv = gfdm_amd.AdvancedReceiver(M, K, L, g["taps"], np.arange(K), n, R.qpsk_points(), decision=decision)
+            assert rel_err(adv.demodulate(g["frames"]), rounds[n - 1]) < TOL                   # MF + IC
+            assert rel_err(adv.demodulate_equalize(frames_ch, feq), rounds[n - 1]) < 2 * TOL   # ZF + IC (channel applied and removed)
+        padv = gfdm_python.AdvancedReceiver(M, K, L, g["taps"], list(range(K)), n, qp, 0)
+        assert rel_err(padv.demodulate(g["frames"]), rounds[n - 1]) < TOL
+    assert_places(padv.demodulate(g["frames"]), rounds[-1], 5)
 
 
 # ---------------------------------------------------------------- the reference's own binding tests, restated
@@ -211,7 +247,7 @@ def test_advanced_receiver_against_oracle(M, K, L, alpha, pc):
     x = R.modulate(d.reshape(B, N), nt, M, K, L)
     feq = np.fft.fft(np.array([1, .5, .1j, .1 + .05j]), N)[None, :] * np.exp(0.01j * np.arange(B))[:, None]
     xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
-    checked = 0
+    checked = checked_mf = 0
     for ic_iter in (0, 1, 2, 5):
         for kind, pts in (("qpsk", R.qpsk_points()), ("nearest", R.qpsk_points() * np.exp(0.1j))):
             adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, ic_iter, pts, do_phase_compensation=pc,
@@ -222,10 +258,13 @@ def test_advanced_receiver_against_oracle(M, K, L, alpha, pc):
             keep = guarded(st, smap, K, M) if ic_iter > 0 else np.ones(B, bool)
             checked += int(keep.sum())
             assert rel_err(got[keep], ref[keep]) < (TOL if pc == 0 else 5 * TOL)
-            ref0 = R.advanced_receive(x, nt, M, K, L, smap, pts, ic_iter, do_phase_compensation=pc, kind=kind)
+            # the unequalised (MF) input through the same receiver: its own stages, its own decision guard
+            ref0, st0 = R.advanced_receive(x, nt, M, K, L, smap, pts, ic_iter, do_phase_compensation=pc, kind=kind, return_stages=True)
             got0 = adv.demodulate(x)
-            assert rel_err(got0[keep], ref0[keep]) < (TOL if pc == 0 else 5 * TOL) or ic_iter > 0
-    assert checked >= 6 * B        # the guard may drop a few blocks, never most of them
+            keep0 = guarded(st0, smap, K, M) if ic_iter > 0 else np.ones(B, bool)
+            checked_mf += int(keep0.sum())
+            assert rel_err(got0[keep0], ref0[keep0]) < (TOL if pc == 0 else 5 * TOL)
+    assert checked >= 6 * B and checked_mf >= 6 * B        # the guard may drop a few blocks, never most of them
 
 
 # ---------------------------------------------------------------- device-pointer (batched, asynchronous) entry points
@@ -281,7 +320,7 @@ def test_empty_and_ragged_batches():
 
 # ---------------------------------------------------------------- full BASELINE sizes: size-independent properties
 
-FULL = [("cfg2", 9, 64, 2, 0.2, 4096), ("cfg4", 15, 128, 4, 0.2, 8192), ("cfg5", 31, 256, 2, 0.1, 2048)]
+FULL = [("cfg2", 9, 64, 2, 0.2, 4096), ("cfg4", 15, 128, 4, 0.2, 8192), ("cfg5", 31, 256, 2, 0.1, 8192)]     # cfg4 / cfg5: the per-GPU share of 65 536 blocks
 
 
 @pytest.mark.parametrize("name,M,K,L,alpha,B", FULL)
@@ -312,6 +351,14 @@ def test_full_size_properties(name, M, K, L, alpha, B):
     assert rel_err(y[pick].cpu().numpy(), R.demodulate(x[pick].cpu().numpy(), nt, M, K, L)) < TOL
     ref_ic = R.advanced_receive(xe[pick].cpu().numpy(), nt, M, K, L, np.arange(K), R.qpsk_points(), 2, f_eq=feq[pick].cpu().numpy(), kind="qpsk")
     assert rel_err(z[pick].cpu().numpy(), ref_ic) < TOL
+    # MF + IC (BASELINE configs[3]'s stated mode): the unequalised frames through the IC receiver, strict against the oracle
+    zmf = adv.demodulate(x)
+    torch.cuda.synchronize()
+    ref_mf, st_mf = R.advanced_receive(x[pick].cpu().numpy(), nt, M, K, L, np.arange(K), R.qpsk_points(), 2, kind="qpsk", return_stages=True)
+    keep = guarded(st_mf, np.arange(K), K, M)
+    assert keep.sum() >= len(pick) - 1
+    assert rel_err(zmf[pick].cpu().numpy()[keep], ref_mf[keep]) < TOL
+    assert bool(torch.all(torch.sign(zmf.real) == torch.sign(sym.real))) and bool(torch.all(torch.sign(zmf.imag) == torch.sign(sym.imag)))
     # equaliser round trip over the whole batch (fp32 channel application + division: 1e-4 is its own noise floor)
     assert float((ye - y).abs().max() / y.abs().max()) < 1e-4
     # IC loop-back: every symbol of every block lands on the transmitted constellation point's quadrant and close to it
@@ -343,6 +390,40 @@ def test_baseline_shapes_run_on_the_tuned_family():
         assert gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points()).kernel_name() == "rowlane"
     taps = get_frequency_domain_filter("rrc", 0.35, 25, 96, 2)
     assert gfdm_amd.Demodulator(25, 96, 2, taps).kernel_name() == "generic_lds"
+
+
+@pytest.mark.parametrize("M,K,L,alpha", SHAPES[:4])
+def test_generic_family_on_the_tuned_shapes(M, K, L, alpha):
+    """The generic kernel family forced (test hook) onto BASELINE shapes 1-5: every mode against the oracle and against the row-lane
+    family, so both HIP families are checked on the same inputs."""
+    import gfdm_amd
+    rng = np.random.default_rng(M + K)
+    taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    N, B = M * K, 9
+    allk = np.arange(K)
+    with gfdm_amd.generic_family_for_testing():
+        gmod, gdem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+        gadv = gfdm_amd.AdvancedReceiver(M, K, L, taps, allk, 2, R.qpsk_points())
+    rmod, rdem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    radv = gfdm_amd.AdvancedReceiver(M, K, L, taps, allk, 2, R.qpsk_points())
+    assert (gmod.kernel_name(), gdem.kernel_name(), gadv.kernel_name()) == ("generic_lds",) * 3
+    assert (rmod.kernel_name(), rdem.kernel_name(), radv.kernel_name()) == ("rowlane",) * 3
+    d = qpsk(rng, (B, N))
+    x = R.modulate(d, nt, M, K, L)
+    feq = np.fft.fft(np.array([1, .5, .1j, .1 + .05j]), N)[None, :] * np.exp(0.01j * np.arange(B))[:, None]
+    xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
+    assert rel_err(gmod.modulate(d), x) < TOL and rel_err(gmod.modulate(d), rmod.modulate(d)) < TOL
+    assert rel_err(gdem.demodulate(x), R.demodulate(x, nt, M, K, L)) < TOL
+    assert rel_err(gdem.demodulate_equalize(xe, feq), rdem.demodulate_equalize(xe, feq)) < TOL
+    assert rel_err(gdem.fft_equalize_filter_downsample(xe, feq), R.fft_filter_downsample(xe, nt, M, K, L, feq)) < TOL
+    for inp, eq in ((x, None), (xe, feq)):
+        ref, st = R.advanced_receive(inp, nt, M, K, L, allk, R.qpsk_points(), 2, f_eq=eq, kind="qpsk", return_stages=True)
+        keep = guarded(st, allk, K, M)
+        assert keep.sum() >= B - 1
+        g = gadv.demodulate(inp) if eq is None else gadv.demodulate_equalize(inp, eq)
+        r = radv.demodulate(inp) if eq is None else radv.demodulate_equalize(inp, eq)
+        assert rel_err(g[keep], ref[keep]) < TOL and rel_err(r[keep], ref[keep]) < TOL
 
 
 def test_ic_with_complex_asymmetric_taps_uses_general_convolution():
