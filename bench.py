@@ -1,69 +1,167 @@
 #!/usr/bin/env python3
-"""bench.py -- GFDM blocks/s on MI355X for BASELINE.json configs[1]: K=64 subcarriers, M=9 timeslots, RRC alpha=0.2,
-overlap=2, batch = 4096 blocks per step, modulate + matched-filter demodulate ("mod+demod").
+"""bench.py -- GFDM blocks/s on MI355X for the BASELINE.json configurations.
 
-One STEP = one pass of the hot path over one batch that is already resident in HBM:
-    frames = modulate(symbols)            (HIP kernel 1)
-    out    = demodulate(frames)           (HIP kernel 2, the dominant one: `roofline` describes it)
-Steps rotate through a ring of distinct device buffers (default >= 2 GiB) so that consecutive steps cannot be
-served from the 256 MiB Infinity Cache.  W warm-up steps, then exactly K timed steps bracketed by barrier +
-synchronize on both sides; the time is the MAX over ranks; `value` = all blocks all ranks processed / that time.
-Every rank processes its own 4096-block batches (weak scaling, no data-path collective: GFDM blocks are independent).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
+
+--config (default cfg2 = BASELINE configs[1], the configuration the headline metric is quoted on):
+    cfg2  K=64  M=9  L=2 alpha=0.2   step = modulate + MF demodulate of 4096 blocks PER GPU           (weak scaling)
+    cfg3  K=64  M=9  L=2 alpha=0.2   step = ZF demodulate + 2 IC iterations of 4096 blocks PER GPU    (weak; north-star path)
+    cfg4  K=128 M=15 L=4 alpha=0.2   step = MF demodulate + 2 IC iterations of 65 536 blocks IN TOTAL (strong: sharded over the GPUs)
+    cfg5  K=256 M=31 L=2 alpha=0.1   step = ZF demodulate of 65 536 blocks IN TOTAL                   (strong)
+
+--gpus N > 1 without a torchrun environment: this process starts N ranks itself (python -m torch.distributed.run, one rank
+per GPU, rendezvous on 127.0.0.1) BEFORE anything touches the GPU and exits with their status.  Under torchrun (WORLD_SIZE
+set, as the driver launches it) it is one of the ranks.  GFDM blocks are independent, so the batch shards contiguously
+(gfdm_amd.sharding.shard_range) with NO data-path collective; RCCL carries the barriers, the max-over-ranks time and an output
+checksum (all-reduced, so the N = 1 and N = 8 runs of a strong-scaled config can be compared).
+
+One STEP = one pass of the hot path over one batch that is already resident in HBM.  Steps rotate through a ring of distinct
+device buffers so that consecutive steps cannot be served from the 256 MiB Infinity Cache.  W warm-up steps, then exactly K
+timed steps bracketed by barrier + synchronize on both sides; the time is the MAX over ranks; `value` = all blocks all ranks
+processed / that time.
 
 Beside the headline the JSON line carries
-  roofline      achieved HBM GB/s of the dominant kernel = algorithmic bytes per launch (16 B/symbol for MF,
-                24 B/symbol with the per-block equaliser vector) / its mean duration measured with
-                HIP events on the launch stream around every launch of the timed region (this includes ~2-3 us of
-                dispatch latency per launch that rocprofv3's kernel trace does not count: profiles/README.md)
-  cpu_baseline  the plain-C oracle ("port" of the reference algorithm, oracle/gfdm_oracle.c) timed on this host's cores
-                on a bounded sample of the same workload (rank 0, N=1 only)
-  paths         the same measurement for each receiver variant (MF, ZF, ZF + 2 IC iterations = configs[2], the
-                north-star path) and the modulator, each over its own ring
+  roofline        achieved HBM GB/s of the step's dominant (slowest) kernel = algorithmic bytes per launch (16 B/symbol,
+                  24 B/symbol with the per-block equaliser vector) / its mean duration, measured with HIP
+                  events on the launch stream around a back-to-back run of the timed steps' launches; `traffic` = HBM bytes per
+                  launch from the committed rocprofv3 PMC summary of the newest profiles/rNN/ (null when it has no row for this
+                  kernel and batch); `copy_ceiling_GBps` = a plain device copy of the same byte count timed the same way
+  roofline_kernels  the same figures for every kernel of the step (cfg2: modulate and demodulate)
+  sustained       the headline loop again for >= 2 s (the default 200 steps are a ~4 ms burst; boxes boost for short bursts)
+  single_block_host_us   one generic_work(out, in) with HOST pointers through the pybind11 drop-in class (H2D + kernel + D2H +
+                  sync): what an unchanged GNU Radio wrapper pays per block, beside the CPU port's per-block time
+  cpu_baseline    the plain-C oracle ("port" of the reference algorithm) on this host: pinned pthreads, one kernel object per
+                  thread (oracle/gfdm_oracle_bench.c), all CPUs this process may run on; single thread beside it
+  paths / large_batch   (N = 1, cfg2 / cfg3 only) every receiver variant and the modulator alone on the stream, and the same
+                  kernels at 65 536 blocks per launch
 """
 import argparse
 import ctypes
 import ctypes.util
+import csv
 import gc
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "gr-gfdm_amd", "python"))
 
-import numpy as np
-import torch
-import torch.distributed as dist
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy reaches
 
-HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a float4 copy reaches
+# mode: kernels of a step; total: blocks of the whole job (strong scaling) or None (batch per GPU, weak scaling)
+CONFIGS = {
+    "cfg2": dict(K=64, M=9, L=2, alpha=0.2, mode="mod_demod_mf", batch=4096, total=None,
+                 metric="GFDM blocks/s, K=64 M=9 mod+demod (MF), batch 4096 per GPU",
+                 workload="BASELINE configs[1]: K=64 subcarriers, M=9 timeslots, RRC alpha=0.2, overlap=2, MF receiver, step = modulate + demodulate"),
+    "cfg3": dict(K=64, M=9, L=2, alpha=0.2, mode="zf_ic2", batch=4096, total=None,
+                 metric="GFDM blocks/s, K=64 M=9 ZF demod + IC x2, batch 4096 per GPU",
+                 workload="BASELINE configs[2]: K=64, M=9, RRC alpha=0.2, overlap=2, one-tap ZF equaliser + advanced receiver with 2 IC iterations"),
+    "cfg4": dict(K=128, M=15, L=4, alpha=0.2, mode="mf_ic2", batch=None, total=65536,
+                 metric="GFDM blocks/s, K=128 M=15 L=4 MF demod + IC x2, 65536 blocks sharded over the GPUs",
+                 workload="BASELINE configs[3]: K=128, M=15, overlap=4 (RRC alpha=0.2), MF + advanced receiver with 2 IC iterations, 65536 blocks in total"),
+    "cfg5": dict(K=256, M=31, L=2, alpha=0.1, mode="zf", batch=None, total=65536,
+                 metric="GFDM blocks/s, K=256 M=31 ZF demod, 65536 blocks sharded over the GPUs",
+                 workload="BASELINE configs[4]: K=256, M=31, RRC alpha=0.1, overlap=2, one-tap ZF equalised demodulation, 65536 blocks in total"),
+}
+# per mode: (uses the equaliser vector, IC iterations, algorithmic bytes per symbol of the receiver launch, cpu driver mode)
+MODES = {"mod_demod_mf": (False, 0, 16, "mod_demod"), "zf_ic2": (True, 2, 24, "demod_ic"), "mf_ic2": (False, 2, 16, "demod_ic"),
+         "zf": (True, 0, 24, "demod")}
+GEN_CHUNK = 8192              # blocks per chunk of the on-device input generation (bounds its temporaries)
 
-CFG = dict(K=64, M=9, L=2, alpha=0.2)
 
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="GFDM blocks per step and per GPU (configs[1]: 4096)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 for the strong-scaled cfg4 / cfg5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; 3 for cfg4 / cfg5)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--batch", type=int, default=None, help="override: blocks per step and per GPU (weak configs) or in total (strong configs)")
     ap.add_argument("--ring-mib", type=int, default=2048, help="total footprint of the buffer ring per path")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps of the headline loop are pipelined over")
     ap.add_argument("--large-batch", type=int, default=65536, help="blocks per launch of the extra large-batch measurement (0 = skip)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained run of the headline loop (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the per-variant measurements")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of each cpu_baseline leg")
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of each cpu_baseline leg")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="no GPU, no GFDM compute: run launcher + rendezvous (gloo) + shard plan + synthetic-input checksum all-reduce "
+                         "and print them (tests/test_bench_launcher.py)")
+    a = ap.parse_args(argv)
+    strong = CONFIGS[a.config]["total"] is not None
+    if a.steps is None:
+        a.steps = 20 if strong else 200
+    if a.warmup is None:
+        a.warmup = 3 if strong else 20
+    return a
 
 
-class Ring:
-    """Ring of device buffers for one path; slot s holds a full batch of inputs and its output."""
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N without a torchrun environment starts the N ranks as a CHILD process (never an exec, and before this
+# process has imported torch, let alone touched a GPU) and exits with its status
 
-    def __init__(self, nslots, make_inputs, batch, N, device):
-        self.inputs = [make_inputs(s) for s in range(nslots)]
-        self.outs = [torch.empty(batch, N, dtype=torch.complex64, device=device) for _ in range(nslots)]
-        self.n = nslots
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+
+def shard_plan(cfg, batch_override, rank, world):
+    """(blocks of this rank per step, first global block of this rank, total blocks per step, 'weak' | 'strong')"""
+    from gfdm_amd import sharding
+    if cfg["total"] is None:
+        B = batch_override or cfg["batch"]
+        return B, None, B * world, "weak"
+    total = batch_override or cfg["total"]
+    start, count = sharding.shard_range(total, rank, world)
+    return count, start, total, "strong"
+
+
+def slot_block_start(plan, rank, slot):
+    """first global block index of this rank's batch in ring slot `slot`: strong -> slot * total + shard start (slot 0 of all
+    ranks together is exactly blocks [0, total), whatever N is); weak -> a range of its own per rank and slot"""
+    B, start, total, scaling = plan
+    return slot * total + start if scaling == "strong" else (rank * 1000003 + slot) * B
+
+
+def selftest_launch(a, cfg, rank, world):
+    """Launcher / rendezvous / shard plan / stat reduction without a GPU: the ranks generate the synthetic symbols of their
+    shard of slot 0 on the CPU (integer hashing, no GFDM arithmetic) and all-reduce their checksum."""
+    import torch
+    import torch.distributed as dist
+    from gfdm_amd import sharding, synth
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = shard_plan(cfg, a.batch, rank, world)
+    B, start, total, scaling = plan
+    N = cfg["K"] * cfg["M"]
+    sym = synth.qpsk_symbols(slot_block_start(plan, rank, 0), B, N, torch.device("cpu"))
+    nblocks, chk, tmax = sharding.reduce_stats(B, sharding.output_checksum(sym), 0.001 * (rank + 1), torch.device("cpu"))
+    ranges = [None] * world
+    if world > 1:
+        dist.all_gather_object(ranges, (slot_block_start(plan, rank, 0), B))
+    else:
+        ranges = [(slot_block_start(plan, rank, 0), B)]
+    if rank == 0:
+        print(json.dumps({"selftest": True, "config": a.config, "n_gpus": world, "scaling": scaling, "blocks_per_step": nblocks,
+                          "shards": ranges, "input_checksum": [float(v) for v in chk], "max_elapsed": tmax}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def raw_launcher(fn, handle, out_t, in_ts, nblocks, stream_ptr):
@@ -78,18 +176,19 @@ def raw_launcher(fn, handle, out_t, in_ts, nblocks, stream_ptr):
     return go
 
 
-def timed_loop(step_fns, dominant, steps, warmup, world, time_kernel=True):
+def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
     """Run warmup + `steps` timed steps.  step_fns[i] is the list of launch closures of ring slot i (each closure is bound
-    to its stream); `dominant` is the index (within a step) of the kernel the roofline describes.  With `time_kernel`
-    (single-stream loops only) ONE HIP event pair on the launch stream brackets a back-to-back run of the `steps` launches
-    of that kernel, i.e. the launch-to-launch duration: the kernel itself plus the ~1.3 us dispatch gap between two
-    dependent launches (an event pair around every single launch would add another ~2.6 us of event packets to each).
-    Returns (wall seconds of the timed region, mean duration in ms of the dominant kernel or None)."""
+    to its stream).  With `time_kernels` (single-stream loops only) every kernel of the step is then replayed alone over the same
+    ring slots with ONE HIP event pair on the launch stream around the back-to-back run of its `steps` launches, i.e. the
+    launch-to-launch duration: the kernel itself plus the ~1.3 us dispatch gap between two dependent launches (an event pair
+    around every single launch would add another ~2.6 us of event packets to each).
+    Returns (wall seconds of the timed region, [mean duration in ms of kernel j of a step] or None)."""
+    import torch
+    import torch.distributed as dist
     nslots = len(step_fns)
     for i in range(warmup):
         for f in step_fns[i % nslots]:
             f()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     gc.collect()
     gc.disable()                              # no collector pause (tens of ms with the tensor rings alive) inside the timed region
     torch.cuda.synchronize()
@@ -97,36 +196,84 @@ def timed_loop(step_fns, dominant, steps, warmup, world, time_kernel=True):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if time_kernel:
-        e0.record()
     for i in range(steps):
         for f in step_fns[(warmup + i) % nslots]:
             f()
-    if time_kernel:
-        e1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0           # this rank's time for its K steps; the caller takes the MAX over ranks
     gc.enable()
     if world > 1:
         dist.barrier()                        # closing bracket: every rank has finished before anyone moves on
     torch.cuda.synchronize()
-    kern_ms = None
-    if time_kernel:
-        if len(step_fns[0]) > 1:          # several kernels per step: replay only the dominant one over the same ring slots
-            e0.record()
-            for i in range(steps):
-                step_fns[(warmup + i) % nslots][dominant]()
-            e1.record()
-            torch.cuda.synchronize()
-        kern_ms = e0.elapsed_time(e1) / steps
+    if not time_kernels:
+        return wall, None
+    kern_ms = []
+    for j in range(len(step_fns[0])):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(min(warmup, 4)):
+            step_fns[i % nslots][j]()
+        e0.record()
+        for i in range(steps):
+            step_fns[(warmup + i) % nslots][j]()
+        e1.record()
+        torch.cuda.synchronize()
+        kern_ms.append(e0.elapsed_time(e1) / steps)
     return wall, kern_ms
 
 
-def cpu_baseline(taps, batch_blocks, seconds):
-    """Time the plain-C oracle (reference algorithm, restated; FFTW/VOLK are not installed) on mod + MF demod.
-    Leg 1: one kernel object, one thread, block by block (how simple_receiver_cc_impl::work drives the reference).
-    Leg 2: T threads, one kernel object each, disjoint block ranges, T = the cores this process may run on.
-    Both legs are time-bounded (`seconds` each) so the default bench run stays within minutes."""
+def copy_ceiling(nbytes_moved, steps, ring_mib, dev):
+    """GB/s of a plain device-to-device copy that moves the same number of bytes (half read, half written) as one launch of the
+    dominant kernel, timed like it (back to back over a ring, one event pair)."""
+    import torch
+    n = max(1, nbytes_moved // 2)
+    nslots = max(2, min(64, (ring_mib << 20) // (2 * n)))
+    src = [torch.empty(n, dtype=torch.uint8, device=dev).random_(0, 255) for _ in range(nslots)]
+    dst = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(nslots)]
+    for i in range(4):
+        dst[i % nslots].copy_(src[i % nslots])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(steps):
+        dst[i % nslots].copy_(src[i % nslots])
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n / (e0.elapsed_time(e1) / steps * 1e-3) / 1e9
+
+
+def pmc_traffic(kernel_template, batch):
+    """HBM bytes per launch of `kernel_template` at `batch` blocks from the newest committed rocprofv3 PMC summary
+    (profiles/rNN/pmc_hbm_traffic_summary.csv, rows `<run>_<batch>` per counter and kernel; FETCH_SIZE x 2 [gfx950 correction
+    for this access width, calibrated on a copy kernel of the same shape -- MI355X_MICROARCH.md, HBM] + WRITE_SIZE, KiB).
+    Counters cannot be read from inside this process; None when the summary has no row for this kernel and batch."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_hbm_traffic_summary.csv")), reverse=True):
+        fetch = write = None
+        try:
+            for row in csv.DictReader(open(path)):
+                if row["kernel"].replace(" ", "") != kernel_template.replace(" ", "") or not row["run"].endswith("_%d" % batch):
+                    continue
+                if row["counter"] == "FETCH_SIZE":
+                    fetch = float(row["mean_KiB"])
+                elif row["counter"] == "WRITE_SIZE":
+                    write = float(row["mean_KiB"])
+        except (OSError, KeyError, ValueError):
+            continue
+        if fetch is not None and write is not None:
+            return {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT)}
+    return None
+
+
+def allowed_cpus():
+    try:
+        return sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return list(range(os.cpu_count() or 1))
+
+
+def cpu_baseline(cfg, taps, seconds):
+    """The plain-C oracle (reference algorithm, restated; FFTW/VOLK are not installed) on this config's step, driven by
+    oracle/gfdm_oracle_bench.c: pinned pthreads, one kernel object each, block after block (how the reference's GNU Radio
+    wrappers drive its kernels) until a common deadline.  Leg 1: one thread.  Leg 2: one thread per CPU this process may run on."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     try:    # rebuild for this host's ISA; fall back to the shipped portable build
@@ -135,76 +282,83 @@ def cpu_baseline(taps, batch_blocks, seconds):
         lib = c_oracle.load(path)
     except Exception:
         lib = c_oracle.load()
-    K, M, L = CFG["K"], CFG["M"], CFG["L"]
-    N = K * M
-    rng = np.random.default_rng(0)
-    nb = 1024
-    sym = (((1 - 2 * rng.integers(0, 2, (nb, N))) + 1j * (1 - 2 * rng.integers(0, 2, (nb, N)))) / np.sqrt(2)).astype(np.complex64)
-
-    def run(o, deadline, counter, idx):
-        n = 0
-        while True:
-            o.demodulate(o.modulate(sym))
-            n += nb
-            if time.perf_counter() >= deadline:
-                break
-        counter[idx] = n
-
-    def leg(nthreads):
-        objs = [c_oracle.COracle(M, K, L, taps, lib=lib) for _ in range(nthreads)]
-        counter = [0] * nthreads
-        t0 = time.perf_counter()
-        deadline = t0 + seconds
-        threads = [threading.Thread(target=run, args=(objs[i], deadline, counter, i)) for i in range(nthreads)]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        return sum(counter) / (time.perf_counter() - t0), sum(counter)
-
-    single, n1 = leg(1)
-    try:
-        T = len(os.sched_getaffinity(0))
-    except AttributeError:
-        T = os.cpu_count() or 1
-    T = max(1, min(T, 64))
-    multi, nT = leg(T)
-    model = ""
+    K, M, L = cfg["K"], cfg["M"], cfg["L"]
+    use_eq, ic_iter, _, cmode = MODES[cfg["mode"]]
+    cpus = allowed_cpus()
+    chunk = max(1, 16384 // (K * M) * 4)
+    n1, t1 = c_oracle.bench_threads(M, K, L, taps, cmode, 1, seconds, use_eq=use_eq, ic_iter=ic_iter, cpus=cpus, chunk=chunk, lib=lib)
+    T = len(cpus)
+    nT, tT = c_oracle.bench_threads(M, K, L, taps, cmode, T, seconds, use_eq=use_eq, ic_iter=ic_iter, cpus=cpus, chunk=chunk, lib=lib)
+    model, phys = "", set()
     try:
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
+            if line.startswith("model name") and not model:
                 model = line.split(":", 1)[1].strip()
-                break
+        for c in cpus:
+            phys.add(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip())
     except OSError:
         pass
-    return {"value": multi, "unit": "blocks/s", "cores": T, "kind": "port",
-            "sample": "mod + MF demod of %d QPSK blocks (K=64 M=9 L=2) in %.0f s on %d threads, one plain-C oracle kernel object "
-                      "per thread (-O3 -march=native); single thread: %d blocks in %.0f s" % (nT, seconds, T, n1, seconds),
-            "single_thread_value": single, "cpu_model": model, "host_logical_cpus": os.cpu_count(),
+    return {"value": nT / tT, "unit": "blocks/s", "cores": T, "kind": "port",
+            "sample": "%s of QPSK blocks (K=%d M=%d L=%d) for %.1f s on %d pinned pthreads, one plain-C oracle kernel object per thread "
+                      "(-O3 -march=native, oracle/gfdm_oracle_bench.c): %d blocks; single thread: %d blocks in %.1f s"
+                      % (cfg["mode"], K, M, L, tT, T, nT, n1, t1),
+            "single_thread_value": n1 / t1, "single_thread_us_per_block": 1e6 * t1 / n1,
+            "cpu_model": model, "host_logical_cpus": os.cpu_count(), "physical_cores_used": len(phys) or None,
             # the reference's own CPU kernels need FFTW3f and VOLK; neither is installed on the boxes of this pool (probe),
             # so the only CPU figure is the plain-C restatement of the same per-block algorithm
             "reference_libs_present": {"fftw3f": ctypes.util.find_library("fftw3f") is not None, "volk": ctypes.util.find_library("volk") is not None}}
 
 
+def single_block_host(cfg, taps, reps=300):
+    """One block through the literal drop-in path: gfdm_python.Demodulator.demodulate(ndarray) = receiver_kernel_cc::generic_work
+    with host pointers (H2D copy, kernel, D2H copy, stream sync) -- what gr-gfdm's unchanged wrappers call once per block
+    (lib/simple_receiver_cc_impl.cc:70-74)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "gr-gfdm_amd", "lib"))
+    import gfdm_python
+    K, M, L = cfg["K"], cfg["M"], cfg["L"]
+    dem = gfdm_python.Demodulator(M, K, L, taps)
+    x = (np.random.default_rng(0).standard_normal(K * M) + 0j).astype(np.complex64)
+    for _ in range(20):
+        dem.demodulate(x)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dem.demodulate(x)
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    cfg = CONFIGS[a.config]
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a, argv))                   # children do the work; nothing in THIS process has touched a GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.selftest_launch:
+        return selftest_launch(a, cfg, rank, world)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels have no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL; only barriers/stat reductions
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL; only barriers / stat reductions
 
     import gfdm_amd
     from gfdm_amd import sharding, synth
     from gfdm_amd.filters import get_frequency_domain_filter
 
-    K, M, L = CFG["K"], CFG["M"], CFG["L"]
-    N, B = K * M, a.batch
-    taps = get_frequency_domain_filter("rrc", CFG["alpha"], M, K, L)
+    K, M, L = cfg["K"], cfg["M"], cfg["L"]
+    N = K * M
+    use_eq, ic_iter, rx_bps, _ = MODES[cfg["mode"]]
+    plan = shard_plan(cfg, a.batch, rank, world)
+    B, _, total_per_step, scaling = plan
+    taps = get_frequency_domain_filter("rrc", cfg["alpha"], M, K, L)
     mod = gfdm_amd.Modulator(M, K, L, taps, device=local)
     dem = gfdm_amd.Demodulator(M, K, L, np.conj(taps), device=local)          # rx taps = conj(tx taps)  (matched filter)
     qpsk = np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) / np.sqrt(2)
@@ -212,90 +366,134 @@ def main():
     L_ = gfdm_amd.lib()
     stream = torch.cuda.current_stream().cuda_stream
     buf_bytes = B * N * 8
+    zeros3 = lambda: torch.zeros(3, dtype=torch.float64, device=dev)
 
-    def slots(nbuf):
-        return max(2, min(256, (a.ring_mib << 20) // (nbuf * buf_bytes)))
+    def slots(nbuf, batch_bytes=buf_bytes):
+        return max(2, min(256, (a.ring_mib << 20) // (nbuf * batch_bytes)))
 
-    gblock = lambda s: (rank * 1000003 + s) * B          # distinct global block range per rank and slot
+    def gen_symbols(block_start, count):
+        return torch.cat([synth.qpsk_symbols(block_start + c, min(GEN_CHUNK, count - c), N, dev) for c in range(0, count, GEN_CHUNK)]) \
+            if count > GEN_CHUNK else synth.qpsk_symbols(block_start, count, N, dev)
 
-    # ---- headline: mod + MF demod -------------------------------------------------------------------------------
+    def gen_rx_inputs(block_start, count, with_eq):
+        """modulated frames (through the per-block test channel when with_eq) of `count` blocks from global block `block_start`"""
+        fr = torch.empty(count, N, dtype=torch.complex64, device=dev)
+        eq = torch.empty(count, N, dtype=torch.complex64, device=dev) if with_eq else None
+        for c in range(0, count, GEN_CHUNK):
+            n = min(GEN_CHUNK, count - c)
+            x = mod.modulate(synth.qpsk_symbols(block_start + c, n, N, dev))
+            if with_eq:
+                f = synth.channel_response(block_start + c, n, N, dev)
+                eq[c:c + n] = f
+                x = synth.through_channel(x, f)
+            fr[c:c + n] = x
+        torch.cuda.synchronize()
+        return fr, eq
+
+    rx_fn, rx_handle = ((L_.gfdm_hip_advanced_receiver_work_device, adv._h) if ic_iter else (L_.gfdm_hip_receiver_demodulate_device, dem._h))
+    rx_template = "k_row_receive<%d, %d, %d, %d, %d, %s>" % (K, M, L, 2 if ic_iter else 1, 1 if use_eq else 0, "true" if ic_iter else "false")
+    mod_template = "k_row_modulate<%d, %d, %d, 0>" % (K, M, L)
+
+    # ---- headline ----------------------------------------------------------------------------------------------------
     # Steps are independent batches (own ring slot each), so they are pipelined over `--streams` HIP streams: slot s always
-    # runs on stream s % S, i.e. within a stream modulate -> demodulate of a slot stay ordered while the load / compute /
-    # store phases of neighbouring steps overlap on the GPU.  `value` is timed on that region.  The `roofline` object is
-    # taken from a single-stream replay of the same steps (one kernel on the GPU at a time): a HIP event pair around the
-    # back-to-back run of the timed steps' demodulate launches (timed_loop).
+    # runs on stream s % S, i.e. within a stream the kernels of a slot stay ordered while the load / compute / store phases of
+    # neighbouring steps overlap on the GPU.  `value` is timed on that region.  The `roofline` objects are taken from a
+    # single-stream replay of the same steps (one kernel on the GPU at a time).
     S = max(1, a.streams)
-    ns = max(S, (slots(3) // S) * S)
-    sym = [synth.qpsk_symbols(gblock(s), B, N, dev) for s in range(ns)]
-    frames = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(ns)]
+    two_kernel = cfg["mode"] == "mod_demod_mf"
+    nbuf = 3 if (two_kernel or use_eq) else 2
+    ns = max(S, (slots(nbuf) // S) * S) if scaling == "weak" else max(2, min(slots(nbuf), 4))
+    if two_kernel:
+        sym = [gen_symbols(slot_block_start(plan, rank, s), B) for s in range(ns)]
+        frames = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(ns)]
+        eqs = [None] * ns
+    else:
+        sym = None
+        frames, eqs = zip(*[gen_rx_inputs(slot_block_start(plan, rank, s), B, use_eq) for s in range(ns)])
     outs = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(ns)]
     side = [torch.cuda.Stream(device=dev) for _ in range(S)]
 
     def step_fns_on(stream_of_slot):
-        return [[raw_launcher(L_.gfdm_hip_modulator_work_device, mod._h, frames[s], [sym[s]], B, stream_of_slot(s)),
-                 raw_launcher(L_.gfdm_hip_receiver_demodulate_device, dem._h, outs[s], [frames[s], None], B, stream_of_slot(s))]
-                for s in range(ns)]
+        fns = []
+        for s in range(ns):
+            step = []
+            if two_kernel:
+                step.append(raw_launcher(L_.gfdm_hip_modulator_work_device, mod._h, frames[s], [sym[s]], B, stream_of_slot(s)))
+            step.append(raw_launcher(rx_fn, rx_handle, outs[s], [frames[s], eqs[s]], B, stream_of_slot(s)))
+            fns.append(step)
+        return fns
 
-    wall, _ = timed_loop(step_fns_on(lambda s: side[s % S].cuda_stream), 1, a.steps, a.warmup, world, time_kernel=False)
-    chk = sharding.output_checksum(outs[(a.warmup + a.steps - 1) % ns])
-    total_blocks, chk, wall_max = sharding.reduce_stats(B * a.steps, chk, wall, dev)
+    piped = step_fns_on(lambda s: side[s % S].cuda_stream)
+    wall, _ = timed_loop(piped, a.steps, a.warmup, world, time_kernels=False)
+    total_blocks, _, wall_max = sharding.reduce_stats(B * a.steps, zeros3(), wall, dev)
     value = total_blocks / wall_max
-    wall1, kern_ms = timed_loop(step_fns_on(lambda s: stream), 1, a.steps, a.warmup, world, time_kernel=True)
-    _, _, wall1_max = sharding.reduce_stats(0, torch.zeros(3, dtype=torch.float64, device=dev), wall1, dev)
-    achieved = 16.0 * N * B / (kern_ms * 1e-3) / 1e9
+    sustained = None
+    if a.sustained_seconds > 0:
+        nsus = max(a.steps, int(a.sustained_seconds / max(wall_max / a.steps, 1e-7)) + 1)
+        wsus, _ = timed_loop(piped, nsus, 0, world, time_kernels=False)
+        sus_blocks, _, wsus_max = sharding.reduce_stats(B * nsus, zeros3(), wsus, dev)
+        sustained = {"seconds": wsus_max, "steps": nsus, "value": sus_blocks / wsus_max, "ms_per_step": wsus_max / nsus * 1e3}
+    single = step_fns_on(lambda s: stream)
+    wall1, kern_ms = timed_loop(single, a.steps, a.warmup, world, time_kernels=True)
+    _, _, wall1_max = sharding.reduce_stats(0, zeros3(), wall1, dev)
+    # output checksum of ring slot 0 (strong scaling: the union over the ranks is global blocks [0, total) whatever N is)
+    for f in single[0]:
+        f()
+    torch.cuda.synchronize()
+    _, chk, _ = sharding.reduce_stats(0, sharding.output_checksum(outs[0]), 0.0, dev)
+
+    names = (["modulate"] if two_kernel else []) + [cfg["mode"] if not two_kernel else "demodulate"]
+    templates = ([mod_template] if two_kernel else []) + [rx_template]
+    bps = ([16] if two_kernel else []) + [rx_bps]
+    rk = {}
+    for nm, tp, bp, ms in zip(names, templates, bps, kern_ms):
+        ach = bp * N * B / (ms * 1e-3) / 1e9
+        tr = pmc_traffic(tp, B)
+        rk[nm] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                  "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
+                  "kernel": tp, "bytes_per_launch": bp * N * B, "kernel_ms": ms}
+    dominant = max(rk, key=lambda k: rk[k]["kernel_ms"])
+    roofline = dict(rk[dominant])
+    roofline["kernel"] = "%s (%s, %s family)" % (roofline["kernel"], dominant, dem.kernel_name())
+    roofline["copy_ceiling_GBps"] = copy_ceiling(roofline["bytes_per_launch"], a.steps, a.ring_mib, dev)
+    roofline["region"] = ("single-stream replay of the %d timed steps' launches of this kernel back to back, one HIP event pair around the "
+                          "run (launch-to-launch time: kernel + dispatch gap; rocprofv3 kernel time: profiles/README.md)" % a.steps)
     result = {
-        "metric": "GFDM blocks/s, K=64 M=9 mod+demod (MF), batch 4096 per GPU",
+        "metric": cfg["metric"],
         "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": wall_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": wall_max / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: K=64 subcarriers, M=9 timeslots, RRC alpha=0.2, overlap=2, MF receiver, "
-                               "%d QPSK blocks per step per GPU, step = modulate + demodulate, ring of %d buffer sets, "
-                               "independent steps pipelined over %d HIP streams" % (B, ns, S),
-                   "block_size": N, "batch_per_gpu": B, "streams": S,
-                   "sharding": "independent blocks per GPU, no data-path collective"},
+        "config": {"workload": "%s; %d QPSK blocks per step %s, ring of %d buffer sets, independent steps pipelined over %d HIP streams"
+                               % (cfg["workload"], total_per_step if scaling == "strong" else B,
+                                  "in total, sharded contiguously over the GPUs" if scaling == "strong" else "per GPU", ns, S),
+                   "name": a.config, "block_size": N, "batch_per_gpu": B, "blocks_per_step_all_gpus": total_per_step, "streams": S,
+                   "sharding": "independent blocks per GPU (gfdm_amd.sharding.shard_range), no data-path collective"},
         "msym_per_s": value * N / 1e6,
-        "value_single_stream": world * B * a.steps / wall1_max,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 [gfx950 correction, calibrated on a
-                     # copy kernel of the same access shape] + WRITE_SIZE; profiles/r01/pmc_hbm_traffic_summary.csv).
-                     # Counters cannot be read from inside this process, so the figure is only quoted for the
-                     # configuration it was measured on.
-                     "traffic": (18576 + 18432) * 1024 if (B == 4096 and dem.kernel_name() == "rowlane") else None,
-                     "kernel": dem.kernel_name() + " (demodulate, MF)", "bytes_per_launch": 16 * N * B,
-                     "kernel_ms": kern_ms,
-                     "region": "single-stream replay of the %d timed steps' demodulate launches back to back, one HIP event pair around "
-                               "the run (launch-to-launch time: kernel + dispatch gap; rocprofv3 kernel time: profiles/README.md)" % a.steps},
+        "value_single_stream": total_per_step * a.steps / wall1_max,
+        "sustained": sustained,
+        "roofline": roofline,
+        "roofline_kernels": rk,
         "kernels": {"modulate": mod.kernel_name(), "demodulate": dem.kernel_name(), "advanced": adv.kernel_name()},
         "output_checksum": [float(v) for v in chk],
     }
-    del sym, frames, outs
+    del sym, frames, eqs, outs, piped, single
 
-    # ---- per-variant measurements (each alone on the stream, own ring) ----------------------------------------------
-    if not a.no_paths:
+    # ---- per-variant measurements (each alone on the stream, own ring): single GPU, K=64 M=9 only ---------------------------
+    want_paths = (not a.no_paths) and world == 1 and a.config in ("cfg2", "cfg3")
+    if want_paths:
         paths = {}
 
         def measure(name, nbuf, bytes_per_sym, make_fns):
             n_slots = slots(nbuf)
             fns, keep = make_fns(n_slots)
-            w, kms = timed_loop(fns, 0, a.steps, a.warmup, world)
-            _, _, wmax = sharding.reduce_stats(0, torch.zeros(3, dtype=torch.float64, device=dev), w, dev)
-            gbps = bytes_per_sym * N * B / (kms * 1e-3) / 1e9
-            paths[name] = {"blocks_per_s": world * B * a.steps / wmax, "msym_per_s": world * B * a.steps / wmax * N / 1e6,
-                           "kernel_ms": kms, "bytes_per_launch": int(round(bytes_per_sym * N * B)), "achieved_GBps": gbps,
+            w, kms = timed_loop(fns, a.steps, a.warmup, world)
+            gbps = bytes_per_sym * N * B / (kms[0] * 1e-3) / 1e9
+            paths[name] = {"blocks_per_s": B * a.steps / w, "msym_per_s": B * a.steps / w * N / 1e6,
+                           "kernel_ms": kms[0], "bytes_per_launch": int(round(bytes_per_sym * N * B)), "achieved_GBps": gbps,
                            "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "ring_slots": n_slots}
             del keep
 
-        def rx_inputs(n_slots, with_eq):
-            fr, eq = [], []
-            for s in range(n_slots):
-                x = mod.modulate(synth.qpsk_symbols(gblock(s), B, N, dev))
-                if with_eq:
-                    f = synth.channel_response(gblock(s), B, N, dev)
-                    x = synth.through_channel(x, f)
-                    eq.append(f)
-                fr.append(x)
-            torch.cuda.synchronize()
-            return fr, eq
+        gblock = lambda s: slot_block_start(plan, rank, s)
 
         def mk_mod(n_slots):
             i = [synth.qpsk_symbols(gblock(s), B, N, dev) for s in range(n_slots)]
@@ -304,9 +502,9 @@ def main():
 
         def mk_rx(fn, handle, with_eq):
             def make(n_slots):
-                fr, eq = rx_inputs(n_slots, with_eq)
+                fr, eq = zip(*[gen_rx_inputs(gblock(s), B, with_eq) for s in range(n_slots)])
                 o = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(n_slots)]
-                return [[raw_launcher(fn, handle, o[s], [fr[s], eq[s] if with_eq else None], B, stream)] for s in range(n_slots)], (fr, eq, o)
+                return [[raw_launcher(fn, handle, o[s], [fr[s], eq[s]], B, stream)] for s in range(n_slots)], (fr, eq, o)
             return make
 
         measure("modulate", 2, 16, mk_mod)
@@ -326,7 +524,7 @@ def main():
         advf.set_channel_estimator(est_)
 
         def mk_chain(n_slots):
-            fr, _ = rx_inputs(n_slots, False)
+            fr = [gen_rx_inputs(gblock(s), B, False)[0] for s in range(n_slots)]
             rp = [torch.tensor(np.tile(pre_, (B, 1)), dtype=torch.complex64, device=dev) for _ in range(n_slots)]
             o = [torch.empty(B, A_ * M, dtype=torch.complex64, device=dev) for _ in range(n_slots)]
 
@@ -347,26 +545,17 @@ def main():
                                 "frac_of_hbm_peak": paths["demod_zf_ic2"]["frac_of_hbm_peak"], "target": 0.40}
 
     # ---- the same kernels at the batch size of BASELINE configs[3,4] (65 536 blocks per launch): steady-state roofline --------
-    if a.large_batch > 0 and not a.no_paths:
+    if a.large_batch > 0 and want_paths:
         BL = a.large_batch
         large = {}
         nsl = 3
-        for name, fn, handle, with_eq, bps in (("demod_mf", L_.gfdm_hip_receiver_demodulate_device, dem._h, False, 16),
-                                               ("demod_zf_ic2", L_.gfdm_hip_advanced_receiver_work_device, adv._h, True, 24)):
-            fr, eq, o = [], [], []
-            for sl in range(nsl):
-                x = mod.modulate(synth.qpsk_symbols(gblock(1000 + sl) , BL, N, dev))
-                if with_eq:
-                    f = synth.channel_response(gblock(1000 + sl), BL, N, dev)
-                    x = synth.through_channel(x, f)
-                    eq.append(f)
-                fr.append(x)
-                o.append(torch.empty(BL, N, dtype=torch.complex64, device=dev))
-            torch.cuda.synchronize()
-            fns = [[raw_launcher(fn, handle, o[sl], [fr[sl], eq[sl] if with_eq else None], BL, stream)] for sl in range(nsl)]
+        for name, fn, handle, with_eq, bps_ in (("demod_mf", L_.gfdm_hip_receiver_demodulate_device, dem._h, False, 16),
+                                                ("demod_zf_ic2", L_.gfdm_hip_advanced_receiver_work_device, adv._h, True, 24)):
+            fr, eq = zip(*[gen_rx_inputs((1000 + sl) * BL, BL, with_eq) for sl in range(nsl)])
+            o = [torch.empty(BL, N, dtype=torch.complex64, device=dev) for _ in range(nsl)]
+            fns = [[raw_launcher(fn, handle, o[sl], [fr[sl], eq[sl]], BL, stream)] for sl in range(nsl)]
             nst = max(10, a.steps // 8)
-            w, kms = timed_loop(fns, 0, nst, 3, world)
-            _, _, wmax = sharding.reduce_stats(0, torch.zeros(3, dtype=torch.float64, device=dev), w, dev)
+            w, kms = timed_loop(fns, nst, 3, world)
             # beside the back-to-back mean, the median of per-launch event pairs: a sustained run of launches of this size makes some
             # boxes of the pool drop their clocks after a few milliseconds (power cap), and idle gaps make them ramp down as well, so
             # the two figures bracket the kernel's duration
@@ -377,15 +566,17 @@ def main():
                 evs[i][1].record()
             torch.cuda.synchronize()
             kms_med = float(np.median([x.elapsed_time(y) for x, y in evs]))
-            gbps = bps * N * BL / (kms * 1e-3) / 1e9
-            large[name] = {"blocks_per_launch": BL, "blocks_per_s": world * BL * nst / wmax, "kernel_ms": kms,
+            gbps = bps_ * N * BL / (kms[0] * 1e-3) / 1e9
+            large[name] = {"blocks_per_launch": BL, "blocks_per_s": BL * nst / w, "kernel_ms": kms[0],
                            "kernel_ms_per_launch_median": kms_med,
-                           "bytes_per_launch": bps * N * BL, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+                           "bytes_per_launch": bps_ * N * BL, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
             del fr, eq, o, fns
         result["large_batch"] = large
 
+    if rank == 0 and world == 1:
+        result["single_block_host_us"] = single_block_host(cfg, np.conj(taps))
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(taps, B, a.cpu_seconds)
+        result["cpu_baseline"] = cpu_baseline(cfg, taps, a.cpu_seconds)
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:

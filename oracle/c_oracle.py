@@ -19,7 +19,8 @@ def build(cflags=None, out=None):
     """(Re)build the shared object; returns its path."""
     out = out or os.path.join(_HERE, "libgfdm_oracle.so")
     cmd = ["gcc"] + (cflags or ["-O3", "-march=x86-64-v3"]) + ["-fPIC", "-std=c11", "-shared", "-o", out,
-                                                              os.path.join(_HERE, "gfdm_oracle.c"), "-lm"]
+                                                              os.path.join(_HERE, "gfdm_oracle.c"),
+                                                              os.path.join(_HERE, "gfdm_oracle_bench.c"), "-lm", "-lpthread"]
     subprocess.check_call(cmd)
     return out
 
@@ -53,6 +54,8 @@ def load(path=None):
     lib.gfdm_oracle_tx_input_vector_size.argtypes = [vp]
     lib.gfdm_oracle_tx_output_vector_size.argtypes = [vp]
     lib.gfdm_oracle_tx_work.argtypes = [vp, vp, vp, ctypes.c_int, lg, ctypes.c_int]
+    lib.gfdm_oracle_bench.restype = lg
+    lib.gfdm_oracle_bench.argtypes = [ctypes.c_int] * 3 + [vp] + [ctypes.c_int] * 5 + [vp, ctypes.c_double, ctypes.c_int, vp]
     del fp, ip
     if path is None:
         _LIB = lib
@@ -120,6 +123,23 @@ class COracle:
         return self._run(self.lib.gfdm_oracle_advanced_receive, x, f_eq,
                          extra=(smap.ctypes.data, smap.size, pts.ctypes.data, pts.size, DECIDE[kind], ic_iter,
                                 do_phase_compensation))
+
+
+BENCH_MODE = {"mod_demod": 0, "demod": 1, "demod_ic": 2}
+
+
+def bench_threads(M, K, L, taps, mode, nthreads, seconds, use_eq=False, ic_iter=0, cpus=None, chunk=32, lib=None):
+    """gfdm_oracle_bench: `nthreads` pinned pthreads, one kernel object each, block after block until the deadline.
+    Returns (blocks processed by all threads, elapsed seconds)."""
+    lib = lib or load()
+    t = _c64(taps)
+    cpu_arr = None if cpus is None else np.ascontiguousarray(cpus[:nthreads], dtype=np.int32)
+    el = ctypes.c_double(0.0)
+    n = lib.gfdm_oracle_bench(M, K, L, t.ctypes.data, t.size, BENCH_MODE[mode], int(bool(use_eq)), int(ic_iter), int(nthreads),
+                              None if cpu_arr is None else cpu_arr.ctypes.data, float(seconds), int(chunk), ctypes.byref(el))
+    if n < 0:
+        raise RuntimeError("gfdm_oracle_bench failed")
+    return int(n), el.value
 
 
 class COracleTx:

@@ -47,6 +47,10 @@ int gfdm_oracle_tx_output_vector_size(const gfdm_oracle_tx* t);
 /* transmitter_kernel::modulate + add_frame for cyclic_shifts[port]; in: nblocks x ninput_size symbols, out: nblocks x output_vector_size */
 void gfdm_oracle_tx_work(gfdm_oracle_tx* t, float* out, const float* in, int ninput_size, long nblocks, int port);
 
+/* ---- timing driver (gfdm_oracle_bench.c): nthreads pinned pthreads, one kernel object each, until a common deadline ---- */
+long gfdm_oracle_bench(int timeslots, int subcarriers, int overlap, const float* taps, int ntaps, int mode, int use_eq, int ic_iter,
+                       int nthreads, const int* cpus, double seconds, int chunk, double* elapsed_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,114 @@
+/* Multi-threaded timing driver of the plain-C CPU oracle (bench.py's cpu_baseline leg).
+ *
+ * TEST / MEASUREMENT INFRASTRUCTURE ONLY -- never linked or called by the product path (see gfdm_oracle.c).
+ *
+ * T pthreads, pinned one per allowed CPU, each with ITS OWN kernel object and private buffers, run the reference's loop
+ * structure -- one kernel object processing its blocks one after the other, exactly how the GNU Radio wrappers drive the
+ * reference kernels (lib/simple_receiver_cc_impl.cc:61-77, lib/simple_modulator_cc_impl.cc:62-80,
+ * lib/advanced_receiver_sb_cc_impl.cc:95-113) -- until a common deadline.  No Python, no GIL, no shared state in the timed
+ * loop: the figure is what the host's cores deliver on this algorithm, not what a Python thread pool lets through. */
+#define _GNU_SOURCE
+#include "gfdm_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+enum { BENCH_MOD_DEMOD = 0, BENCH_DEMOD = 1, BENCH_DEMOD_IC = 2 };
+
+typedef struct {
+    int M, K, L, ntaps, mode, use_eq, ic_iter, chunk, cpu;
+    const float* taps;
+    double deadline;       /* CLOCK_MONOTONIC seconds */
+    long blocks;           /* out */
+    int failed;            /* out */
+} worker_t;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void* worker(void* arg)
+{
+    worker_t* w = (worker_t*)arg;
+    if (w->cpu >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(w->cpu, &set);
+        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    }
+    gfdm_oracle* o = gfdm_oracle_create(w->M, w->K, w->L, w->taps, w->ntaps);
+    const size_t N = (size_t)w->M * (size_t)w->K, n = N * (size_t)w->chunk;
+    float* sym = (float*)malloc(sizeof(float) * 2 * n);
+    float* frames = (float*)malloc(sizeof(float) * 2 * n);
+    float* out = (float*)malloc(sizeof(float) * 2 * n);
+    float* eq = w->use_eq ? (float*)malloc(sizeof(float) * 2 * n) : NULL;
+    int* smap = (int*)malloc(sizeof(int) * (size_t)w->K);
+    if (!o || !sym || !frames || !out || !smap || (w->use_eq && !eq)) { w->failed = 1; return NULL; }
+    uint64_t s = 0x9E3779B97F4A7C15ull * (uint64_t)(w->cpu + 2);
+    const float a = 0.70710678f;
+    for (size_t i = 0; i < 2 * n; ++i) {               /* QPSK symbols */
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        sym[i] = (s >> 40) & 1 ? a : -a;
+    }
+    for (size_t i = 0; i < n && eq; ++i) {             /* a smooth, nowhere-small equaliser vector */
+        const float ph = 6.2831853f * (float)(i % N) / (float)N;
+        eq[2 * i] = 1.0f + 0.4f * cosf(ph);
+        eq[2 * i + 1] = 0.3f * sinf(ph);
+    }
+    for (int k = 0; k < w->K; ++k) smap[k] = k;
+    const float pts[8] = { -a, -a, a, -a, -a, a, a, a };
+    gfdm_oracle_modulate(o, frames, sym, w->chunk);     /* receiver input: modulated frames (decisions well conditioned) */
+    long done = 0;
+    do {
+        if (w->mode == BENCH_MOD_DEMOD) {
+            gfdm_oracle_modulate(o, frames, sym, w->chunk);
+            gfdm_oracle_demodulate(o, out, frames, eq, w->chunk);
+        } else if (w->mode == BENCH_DEMOD) {
+            gfdm_oracle_demodulate(o, out, frames, eq, w->chunk);
+        } else {
+            gfdm_oracle_advanced_receive(o, out, frames, eq, w->chunk, smap, w->K, pts, 4, GFDM_ORACLE_DECIDE_QPSK, w->ic_iter, 0);
+        }
+        done += w->chunk;
+    } while (now_s() < w->deadline);
+    w->blocks = done;
+    free(sym); free(frames); free(out); free(eq); free(smap);
+    gfdm_oracle_destroy(o);
+    return NULL;
+}
+
+/* Runs `nthreads` workers for about `seconds`; thread t is pinned to cpus[t] (cpus == NULL: not pinned).
+ * mode: 0 modulate + demodulate, 1 demodulate, 2 demodulate + ic_iter IC rounds (QPSK, all subcarriers active);
+ * use_eq: with the per-block equaliser vector (generic_work_equalize).  chunk: blocks a worker processes between two looks at
+ * the clock.  Returns the blocks processed by all workers (or -1), *elapsed_s = wall time from start to the last join. */
+long gfdm_oracle_bench(int timeslots, int subcarriers, int overlap, const float* taps, int ntaps, int mode, int use_eq, int ic_iter,
+                       int nthreads, const int* cpus, double seconds, int chunk, double* elapsed_s)
+{
+    if (nthreads < 1 || chunk < 1) return -1;
+    worker_t* w = (worker_t*)calloc((size_t)nthreads, sizeof(worker_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    if (!w || !th) { free(w); free(th); return -1; }
+    const double t0 = now_s();
+    for (int t = 0; t < nthreads; ++t) {
+        w[t] = (worker_t){ timeslots, subcarriers, overlap, ntaps, mode, use_eq, ic_iter, chunk, cpus ? cpus[t] : -1, taps,
+                           t0 + seconds + 0.05 /* thread start-up */, 0, 0 };
+        if (pthread_create(&th[t], NULL, worker, &w[t]) != 0) { w[t].failed = 1; th[t] = 0; }
+    }
+    long total = 0;
+    int failed = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        if (th[t]) pthread_join(th[t], NULL);
+        total += w[t].blocks;
+        failed |= w[t].failed;
+    }
+    if (elapsed_s) *elapsed_s = now_s() - t0;
+    free(w); free(th);
+    return failed ? -1 : total;
+}

@@ -1,0 +1,62 @@
+"""bench.py's multi-rank plumbing on the CPU: `--gpus N` must start N ranks itself (python -m torch.distributed.run on
+127.0.0.1), shard a strong-scaled config with gfdm_amd.sharding.shard_range, and all-reduce the run statistics -- checked through
+bench.py's own code path with `--selftest-launch` (gloo, no GPU, no GFDM arithmetic: the ranks checksum the synthetic input
+symbols of their shard, which are keyed on the global block index)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-launch"] + list(args), env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(600)
+def test_gpus_flag_starts_ranks_and_strong_scaled_config_is_split_invariant():
+    one = run_bench("--config", "cfg4", "--batch", "1001")
+    two = run_bench("--gpus", "2", "--config", "cfg4", "--batch", "1001")
+    three = run_bench("--gpus", "3", "--config", "cfg4", "--batch", "1001")
+    assert (one["n_gpus"], two["n_gpus"], three["n_gpus"]) == (1, 2, 3)
+    assert one["scaling"] == two["scaling"] == "strong"
+    assert one["blocks_per_step"] == two["blocks_per_step"] == three["blocks_per_step"] == 1001        # total work fixed
+    assert two["shards"] == [[0, 501], [501, 500]] and three["shards"] == [[0, 334], [334, 334], [668, 333]]
+    for a, b in zip(one["input_checksum"], two["input_checksum"]):                                     # same global blocks, any split
+        assert abs(a - b) <= 1e-9 * max(1.0, abs(a))
+    for a, b in zip(one["input_checksum"], three["input_checksum"]):
+        assert abs(a - b) <= 1e-9 * max(1.0, abs(a))
+    assert two["max_elapsed"] == pytest.approx(0.002)          # MAX over ranks of the per-rank time
+
+
+@pytest.mark.timeout(600)
+def test_weak_scaled_default_config_grows_with_the_ranks():
+    one = run_bench("--batch", "64")
+    two = run_bench("--gpus", "2", "--batch", "64")
+    assert one["config"] == two["config"] == "cfg2" and two["scaling"] == "weak"
+    assert (one["blocks_per_step"], two["blocks_per_step"]) == (64, 128)
+    assert two["shards"][0][1] == two["shards"][1][1] == 64 and two["shards"][0][0] != two["shards"][1][0]
+
+
+def test_bench_runs_under_an_external_torchrun_environment():
+    """the driver's own launch: torchrun sets WORLD_SIZE, bench.py must then NOT start ranks of its own"""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg5", "--batch", "10",
+                        "--selftest-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["shards"] == [[0, 5], [5, 5]]

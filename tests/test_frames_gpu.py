@@ -86,7 +86,7 @@ def test_frames_against_oracle(M, K, L, alpha, per_ts):
     dem.configure_frames(frame_len, cp)
     assert rel_err(dem.demodulate_frames(frames, feq), R.demodulate(x, nt, M, K, L, feq)) < TOL
     # ... and without a map the kernel writes whole blocks: a truncating noutput_size is refused, never a short buffer overrun
-    with pytest.raises(gfdm_amd.GfdmHipError, match="needs a subcarrier map"):
+    with pytest.raises(ValueError, match="needs a subcarrier map"):
         dem.demodulate_frames(frames, feq, noutput_size=N - 7)
     assert dem.demodulate_frames(frames, feq, noutput_size=N).shape == (B, N)
 
