@@ -309,7 +309,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     GFDM_STAMP(0);
     // ---- phase A: timeslot DFT of row q, twiddle W_N^{q m}
     cf v[M];
-    static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = in[in_base + K * pp + q]; });
+    static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; v[pp] = ld_stream(in + in_base + K * pp + q); });
     FftTwiddles<K> twd;
     load_fft_twiddles<K>(twd, q, p.wK);
     // Everything else the later phases read from global memory is requested here as well: behind an ordering point a load can
@@ -333,8 +333,8 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     cf pre0, pre1, inv0, inv1;
     if constexpr (EQ == EQ_PREAMBLE) {
         const cf* pre = f_eq + (valid ? blk : 0) * (int64_t)(est.pre_stride ? est.pre_stride : 2 * K);
-        pre0 = pre[q];
-        pre1 = pre[K + q];
+        pre0 = ld_stream(pre + q);
+        pre1 = ld_stream(pre + K + q);
         inv0 = est.inv0[q];
         inv1 = est.inv1[q];
     }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
 #ifndef GFDM_EAGER_FEQ
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; heq[i] = f_eq[base + q + K * i]; });
+        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; heq[i] = ld_stream(f_eq + base + q + K * i); });
     }
 
     // ---- phase B: subcarrier FFT, in place
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
             static_for<0, M>([&](auto mi) {
                 constexpr int m = decltype(mi)::value;
                 const int idx = io_per_timeslot ? (m * io_A + a) : (a * M + m);
-                if (idx < io_nout) o[idx] = d[m];
+                if (idx < io_nout) st_stream(o, idx, d[m]);
             });
         }
     } else {
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
         static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = (MODE == RX_FD) ? s[m] : d[m]; });
         block_sync<K>();
         if (valid) {
-            static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; out[base + q + K * i] = X[q + K * i]; });
+            static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; st_stream(out, base + q + K * i, X[q + K * i]); });
         }
     }
     GFDM_STAMP(5);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
     cf v[M];
     if constexpr (TXMODE == 0) {
         // symbols [k][p], copied linearly (coalesced) into the tile; lane k then owns row k
-        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; X[q + K * i] = in[base + q + K * i]; });
+        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; X[q + K * i] = ld_stream(in + base + q + K * i); });
         block_sync<K>();
         static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = X[q * M + m]; });
     } else {
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
             static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; tx_store_sample(tx, blk, N, K * pp + q, v[pp]); });
             tx_store_preamble(tx, blk, q, K);
         } else {
-            static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; out[base + K * pp + q] = v[pp]; });
+            static_for<0, M>([&](auto pi) { constexpr int pp = decltype(pi)::value; st_stream(out, base + K * pp + q, v[pp]); });
         }
     }
 }
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_estimate(EstPlan est, c
     cf* F = X + 2 * K;                                                             // smoothed estimate behind the [K][2] view
 
     const cf* pre = in + (valid ? blk : 0) * (int64_t)(2 * K);
-    const cf p0 = pre[q], p1 = pre[K + q];
+    const cf p0 = ld_stream(pre + q), p1 = ld_stream(pre + K + q);
     const cf inv0 = est.inv0[q], inv1 = est.inv1[q];
     FftTwiddles<K> twd;
     load_fft_twiddles<K>(twd, q, est.wK);
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_estimate(EstPlan est, c
     });
     block_sync<K>();
     if (valid) {
-        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; out[blk * N + q + K * i] = X[q + K * i]; });
+        static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; st_stream(out, blk * N + q + K * i, X[q + K * i]); });
     }
 }
 

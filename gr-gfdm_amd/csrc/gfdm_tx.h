@@ -6,6 +6,7 @@
 // lib/add_cyclic_prefix_cc.cc:66-98 (add_cyclic_extension, apply_ramp), lib/transmitter_kernel.cc:78-107.
 #pragma once
 #include "gfdm_plan.h"
+#include "gfdm_dft.h"
 
 namespace gfdm {
 
@@ -35,7 +36,7 @@ __device__ __forceinline__ cf tx_symbol(const TxParams& t, const cf* __restrict_
     const int a = t.rank[k];
     if (a < 0) return make_float2(0.f, 0.f);
     const int idx = t.per_timeslot ? (ti * t.A + a) : (a * M + ti);
-    return (idx < t.nin) ? in_block[idx] : make_float2(0.f, 0.f);
+    return (idx < t.nin) ? dft::ld_stream(in_block + idx) : make_float2(0.f, 0.f);
 }
 
 __device__ __forceinline__ cf tx_window(const TxParams& t, int f, int N, cf x)
@@ -59,9 +60,9 @@ __device__ __forceinline__ void tx_store_sample(const TxParams& t, int64_t blk, 
         cf* o = t.outs[port] + blk * (int64_t)t.F + t.plen;
         const int s = t.shifts[port];
         const int scp = t.cp + s, scs = t.cs - s;
-        o[scp + n] = tx_window(t, scp + n, N, x);
-        if (n >= N - scp) o[n - (N - scp)] = tx_window(t, n - (N - scp), N, x);
-        if (n < scs) o[scp + N + n] = tx_window(t, scp + N + n, N, x);
+        dft::st_stream(o, scp + n, tx_window(t, scp + n, N, x));
+        if (n >= N - scp) dft::st_stream(o, n - (N - scp), tx_window(t, n - (N - scp), N, x));
+        if (n < scs) dft::st_stream(o, scp + N + n, tx_window(t, scp + N + n, N, x));
     }
 }
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ void tx_store_preamble(const TxParams& t, int64_t blk
     for (int port = 0; port < t.nports; ++port) {
         cf* o = t.outs[port] + blk * (int64_t)t.F;
         const cf* pre = t.preambles + (int64_t)port * t.plen;
-        for (int j = first; j < t.plen; j += step) o[j] = pre[j];
+        for (int j = first; j < t.plen; j += step) dft::st_stream(o, j, pre[j]);
     }
 }
 
