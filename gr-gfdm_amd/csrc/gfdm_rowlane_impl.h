@@ -63,6 +63,14 @@ template <int K> struct RowShape {
     static constexpr int WG = (K >= 128) ? K : GFDM_ROW_WG;   // threads per workgroup (blocks of K <= 64 lanes are packed)
     static constexpr int BPW = WG / K;                     // blocks per workgroup
     static constexpr int RG = K / 4;                       // row groups of the FFT passes
+    // K = 256 = 16 x 16: TWO radix-16 passes instead of four radix-4 passes (lds_subcarrier_fft16): half the LDS traffic and half
+    // the ordering points of the subcarrier FFT, the same butterfly arithmetic.  This shape is LDS-limited to two blocks per CU,
+    // so its launch time is close to the SUM of its HBM, LDS and VALU time rather than their maximum.
+#ifndef GFDM_NO_RADIX16
+    static constexpr bool RADIX16 = (K == 256);
+#else
+    static constexpr bool RADIX16 = false;
+#endif
 };
 
 constexpr int pow4(int s) { return 1 << (2 * s); }
@@ -106,7 +114,11 @@ template <int K> struct EstTile {
 template <int K> struct FftLayout {
     static __device__ __forceinline__ int slot(int row)
     {
-        if constexpr (K >= 64) {
+        if constexpr (RowShape<K>::RADIX16) {
+            // radix-16 passes: 16 neighbouring lanes touch rows tq + 16 r (reads, phase A), 16 tq + u (pass-0 writes); rotating the
+            // low four row bits by the next four keeps the slots of both patterns distinct mod 32 (b64 slots, odd row stride)
+            return (row & ~15) | ((row + (row >> 4)) & 15);
+        } else if constexpr (K >= 64) {
             const int b = (row >> 4) & 3, c = (row >> 2) & 3, d = row & 3;
             return (row & ~63) | (16 * b + 4 * ((c + b) & 3) + ((d + b) & 3));
         } else {
@@ -123,15 +135,21 @@ template <int K> struct FftLayout {
 // (next to the sample loads): loaded inside the passes, each pass would wait for a vector-memory round trip between its LDS reads
 // and writes, because loads cannot be hoisted across the ordering points.
 template <int K> struct FftTwiddles {
-    cf w[RowShape<K>::NP4][3];
+    cf w[RowShape<K>::RADIX16 ? 1 : RowShape<K>::NP4][3];
+    cf w16[RowShape<K>::RADIX16 ? 15 : 1];                 // radix-16: W_K^{tq u}, u = 1 .. 15, of the first pass
 };
 
 template <int K>
 __device__ __forceinline__ void load_fft_twiddles(FftTwiddles<K>& t, int lane, const cf* __restrict__ wK)
 {
     using S = RowShape<K>;
+    if constexpr (S::RADIX16) {
+        const int tq16 = lane % (K / 16);
+        static_for<1, 16>([&](auto ui) { constexpr int u = decltype(ui)::value; t.w16[u - 1] = wK[(tq16 * u) & (K - 1)]; });
+        return;
+    }
     const int tq = lane % S::RG;
-    static_for<0, S::NP4>([&](auto si) {
+    static_for<0, S::RADIX16 ? 0 : S::NP4>([&](auto si) {
         constexpr int s = decltype(si)::value;
         constexpr int str = pow4(s), ms = K / str / 4;
         if constexpr (ms > 1) {
@@ -143,11 +161,53 @@ __device__ __forceinline__ void load_fft_twiddles(FftTwiddles<K>& t, int lane, c
     });
 }
 
+// K = 256: two radix-16 Stockham passes, in place.  Lane (tq, cg), tq = lane % 16, owns rows tq + 16 r (r = 0 .. 15) of column
+// group cg (ceil(M / 16) columns): pass 0 writes rows 16 tq + u with twiddle W_K^{tq u}, pass 1 reads and writes the lane's own
+// rows tq + 16 u and leaves natural order.  The 16-point butterflies are the compile-time codelet Dft<16>.
+template <int K, int M, bool INV>
+__device__ __forceinline__ void lds_subcarrier_fft16(cf* tile, int lane, const FftTwiddles<K>& twd)
+{
+    static_assert(K == 256, "two radix-16 passes");
+    using LY = FftLayout<K>;
+    constexpr int RG = K / 16, CMAX = (M + 15) / 16;
+    const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+    static_for<0, 2>([&](auto si) {
+        constexpr int s = decltype(si)::value;
+        cf x[CMAX][16];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) static_for<0, 16>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
+        });
+        block_sync<K>();                                          // everyone has its inputs in registers
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                Dft<16, INV>::run(x[c]);
+                static_for<0, 16>([&](auto ui) {
+                    constexpr int u = decltype(ui)::value;
+                    if constexpr (s == 0) {
+                        cf y = x[c][u];
+                        if constexpr (u > 0) y = cmul_dir<INV>(y, twd.w16[u - 1]);
+                        tile[LY::slot(16 * tq + u) * M + c0 + c] = y;
+                    } else {
+                        tile[(tq + RG * u) * M + c0 + c] = x[c][u];      // natural order
+                    }
+                });
+            }
+        });
+        block_sync<K>();
+    });
+}
+
 template <int K, int M, bool INV, int FIRST = 0>
 __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const FftTwiddles<K>& twd)
 {
     using S = RowShape<K>;
     using LY = FftLayout<K>;
+    if constexpr (S::RADIX16) {
+        lds_subcarrier_fft16<K, M, INV>(tile, lane, twd);
+        return;
+    }
     constexpr int RG = S::RG, CMAX = (M + 3) / 4;
     const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
     const cf* rb[4];
@@ -158,7 +218,7 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
         constexpr bool last = (s == S::NP4 - 1) && !S::HAS2;      // the pass that leaves the data in natural order
         const int j = tq & (str - 1), qq = tq / str;
         cf w1, w2, w3;
-        if constexpr (ms > 1) { w1 = twd.w[s][0]; w2 = twd.w[s][1]; w3 = twd.w[s][2]; }
+        if constexpr (ms > 1 && !S::RADIX16) { w1 = twd.w[s][0]; w2 = twd.w[s][1]; w3 = twd.w[s][2]; }
         cf* wb[4];
         static_for<0, 4>([&](auto ui) {
             constexpr int u = decltype(ui)::value;
