@@ -13,7 +13,10 @@
     X(64, 5, 2)            \
     X(64, 15, 2)           \
     X(128, 9, 2)           \
-    X(128, 15, 2)
+    X(128, 15, 2)          \
+    X(128, 21, 2)          \
+    X(4, 16, 2)            \
+    X(4, 8, 2)
 
 namespace gfdm {
 
