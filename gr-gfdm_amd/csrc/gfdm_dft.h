@@ -5,7 +5,12 @@
 // Twiddles come from a constexpr sine/cosine evaluated in double with exact octant reduction on the
 // rational angle e/n, so W^0, W^(n/4), W^(n/2) ... are exactly 1, -j, -1 ...
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#include <stdint.h>
+#else
+typedef signed long long int64_t;
+#endif
 #include <type_traits>
 
 namespace gfdm {

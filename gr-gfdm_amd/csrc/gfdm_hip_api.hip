@@ -44,6 +44,8 @@ int fail_hip(hipError_t e, const char* what)
 
 // test hook (gfdm_hip_force_generic_family_for_testing): handles created while it is set use the generic kernel family
 std::atomic<int> g_force_generic{ 0 };
+// gfdm_hip_set_jit: run-time instantiation (hiprtc) of the row-lane kernels for shapes outside the compiled list
+std::atomic<int> g_jit{ 1 };
 
 struct Plan {
     int device = 0;
@@ -190,8 +192,21 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     pl.d_twT = pl.d_tables + twT_off;
     // kernel family: row-lane where the shape is instantiated, else the generic LDS family.  Only the explicit test hook
     // gfdm_hip_force_generic_family_for_testing changes that; no environment variable does.
-    pl.family = (gfdm::rowlane_supports(M, K, L) && !g_force_generic.load()) ? gfdm::FAMILY_ROWLANE : gfdm::FAMILY_GENERIC;
-    pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : "generic_lds";
+    pl.family = gfdm::FAMILY_GENERIC;
+    if (!g_force_generic.load()) {
+        if (gfdm::rowlane_supports(M, K, L)) {
+            pl.family = gfdm::FAMILY_ROWLANE;
+        } else if (g_jit.load() && gfdm::jit_eligible(M, K, L)) {
+            // not in the compiled list: instantiate the row-lane kernels for this shape now (seconds, once per shape and machine --
+            // the code object is cached on disk).  Any failure (no hiprtc, no cache directory AND no compiler, ...) leaves the handle
+            // on the generic HIP family; the reason stays readable from gfdm_hip_last_error().
+            std::string why;
+            DeviceGuard guard(device);
+            if (gfdm::jit_prepare(M, K, L, why)) pl.family = gfdm::FAMILY_ROWLANE_JIT;
+            else g_last_error = "run-time instantiation of the row-lane kernels failed, using the generic family: " + why;
+        }
+    }
+    pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : pl.family == gfdm::FAMILY_ROWLANE_JIT ? "rowlane_jit" : "generic_lds";
     return GFDM_HIP_OK;
 }
 
@@ -254,12 +269,14 @@ hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, cons
                             hipStream_t s, const gfdm::EstPlan* est = nullptr)
 {
     if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    if (pl.family == gfdm::FAMILY_ROWLANE_JIT) return gfdm::jit_launch_receive(pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
     return gfdm::launch_generic_receive(pl.dp, ic, est, mode, out, in, f_eq, nblocks, s);
 }
 
 hipError_t mod_launch(Plan& pl, const gfdm::TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
     if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_modulate(pl.dp, tx, pl.d_twT, out, in, nblocks, s);
+    if (pl.family == gfdm::FAMILY_ROWLANE_JIT) return gfdm::jit_launch_modulate(pl.dp, tx, pl.d_twT, out, in, nblocks, s);
     return gfdm::launch_generic_modulate(pl.dp, tx, out, in, nblocks, s);
 }
 
@@ -369,6 +386,18 @@ const char* gfdm_hip_last_error(void) { return g_last_error.c_str(); }
 int gfdm_hip_force_generic_family_for_testing(int enable)
 {
     return g_force_generic.exchange(enable ? 1 : 0);
+}
+
+int gfdm_hip_set_jit(int enable)
+{
+    return g_jit.exchange(enable ? 1 : 0);
+}
+
+int gfdm_hip_jit_build_for_testing(int timeslots, int subcarriers, int overlap, int part)
+{
+    std::string why;
+    if (gfdm::jit_build_only(timeslots, subcarriers, overlap, part, why)) return GFDM_HIP_OK;
+    return fail(GFDM_HIP_EINVAL, why.c_str());
 }
 
 int gfdm_hip_device_count(void)
@@ -965,6 +994,8 @@ int est_run_device(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, v
     return run_device(c->plan, out, in, nframes, [&]() {
         if (c->plan.family == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
             return gfdm::launch_rowlane_estimate(c->ep, static_cast<cf*>(out), static_cast<const cf*>(in), nframes, static_cast<hipStream_t>(stream));
+        if (c->plan.family == gfdm::FAMILY_ROWLANE_JIT && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
+            return gfdm::jit_launch_estimate(c->ep, static_cast<cf*>(out), static_cast<const cf*>(in), nframes, static_cast<hipStream_t>(stream));
         return gfdm::launch_estimate(c->ep, in_stage, out_stage, static_cast<cf*>(out), static_cast<const cf*>(in), nframes,
                                      static_cast<hipStream_t>(stream));
     });
@@ -978,6 +1009,8 @@ int est_run_host(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, flo
     return run_host_sized(c->plan, out, nout, in, nin, nullptr, 0, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
         if (c->plan.family == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
             return gfdm::launch_rowlane_estimate(c->ep, o, i, nframes, s);
+        if (c->plan.family == gfdm::FAMILY_ROWLANE_JIT && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
+            return gfdm::jit_launch_estimate(c->ep, o, i, nframes, s);
         return gfdm::launch_estimate(c->ep, in_stage, out_stage, o, i, nframes, s);
     });
 }
@@ -1035,8 +1068,13 @@ int gfdm_hip_channel_estimator_create(gfdm_hip_channel_estimator** out, int time
     e.w2K = e.wK + K;
     // estimate_frame runs in the row-lane layout where a shape with this (fft_len, timeslots) is instantiated; the single stages,
     // prepare_for_zf and estimate_snr always use the generic kernels.
-    c->plan.family = (gfdm::rowlane_supports_estimate(timeslots, K) && !g_force_generic.load()) ? gfdm::FAMILY_ROWLANE : gfdm::FAMILY_GENERIC;
-    c->plan.kernel_name = c->plan.family == gfdm::FAMILY_ROWLANE ? "rowlane" : "generic_lds";
+    c->plan.family = gfdm::FAMILY_GENERIC;
+    if (!g_force_generic.load()) {
+        std::string why;
+        if (gfdm::rowlane_supports_estimate(timeslots, K)) c->plan.family = gfdm::FAMILY_ROWLANE;
+        else if (g_jit.load() && gfdm::jit_eligible(timeslots, K, 2) && gfdm::jit_prepare_estimate(timeslots, K, why)) c->plan.family = gfdm::FAMILY_ROWLANE_JIT;
+    }
+    c->plan.kernel_name = c->plan.family == gfdm::FAMILY_ROWLANE ? "rowlane" : c->plan.family == gfdm::FAMILY_ROWLANE_JIT ? "rowlane_jit" : "generic_lds";
     *out = c.release();
     return GFDM_HIP_OK;
 }

@@ -1,7 +1,11 @@
 // Internal: device-side plan shared by the HIP kernel families and the C-ABI shim.
 #pragma once
+#ifndef __HIPCC_RTC__          // hiprtc (run-time instantiation of the row-lane kernels, gfdm_jit.hip) brings its own runtime header
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef signed long long int64_t;
+#endif
 
 namespace gfdm {
 
@@ -59,6 +63,7 @@ enum RxMode {
     RX_IC = 2         // advanced receiver:               out after ic_iter cancellation rounds
 };
 
+#ifndef __HIPCC_RTC__
 // ---- generic family (any M, K, L; one workgroup per block, everything staged in LDS) ----
 size_t generic_lds_bytes(int N, int ntiles);
 struct TxParams;   // gfdm_tx.h: resource mapper in front of / cyclic prefix + preamble behind the modulator
@@ -78,6 +83,20 @@ hipError_t launch_rowlane_modulate(const DevicePlan& p, const TxParams& tx, cons
                                    hipStream_t s);
 hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const EstPlan* est, const cf* twT, int mode, cf* out, const cf* in,
                                   const cf* f_eq, int64_t nblocks, hipStream_t s);
+// ... and the same kernels instantiated at run time (gfdm_jit.hip); jit_prepare* compile / load on the CURRENT device
+hipError_t jit_launch_modulate(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+hipError_t jit_launch_receive(const DevicePlan& p, const IcParams& ic, const EstPlan* est, const cf* twT, int mode, cf* out, const cf* in,
+                              const cf* f_eq, int64_t nblocks, hipStream_t s);
+hipError_t jit_launch_estimate(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s);
+}  // namespace gfdm
+#include <string>
+namespace gfdm {
+bool jit_eligible(int M, int K, int L);
+bool jit_prepare(int M, int K, int L, std::string& err);
+bool jit_prepare_estimate(int M, int K, std::string& err);
+bool jit_build_only(int M, int K, int L, int part, std::string& err);
+
+#endif  // !__HIPCC_RTC__
 
 // Preamble channel estimator (lib/preamble_channel_estimator_cc.cc): tables of one estimator handle.
 struct EstPlan {
@@ -100,6 +119,7 @@ enum EqSource {
     EQ_PREAMBLE = 2       // f_eq points at the received preambles; the kernel runs the channel estimator itself
 };
 
+#ifndef __HIPCC_RTC__
 // stages of the estimator chain; a launch runs in_stage -> out_stage inside one kernel
 enum EstStage { EST_RX_PREAMBLE = 0, EST_PREAMBLE_CHANNEL = 1, EST_FILTERED = 2, EST_FRAME = 3 };
 size_t estimator_lds_bytes(int K);
@@ -110,6 +130,9 @@ hipError_t launch_prepare_for_zf(cf* out, const cf* in, int64_t n, hipStream_t s
 bool rowlane_supports_estimate(int M, int K);
 hipError_t launch_rowlane_estimate(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s);   // rx preamble -> frame
 
-enum KernelFamily { FAMILY_GENERIC = 0, FAMILY_ROWLANE = 2 };
+#endif  // !__HIPCC_RTC__
+
+// FAMILY_ROWLANE_JIT: the row-lane kernels instantiated at run time through hiprtc for a shape outside the compiled list (gfdm_jit.hip)
+enum KernelFamily { FAMILY_GENERIC = 0, FAMILY_ROWLANE = 2, FAMILY_ROWLANE_JIT = 3 };
 
 }  // namespace gfdm

@@ -5,4 +5,4 @@
 """
 from . import filters  # noqa: F401
 from .capi import (AdvancedReceiver, ChannelEstimator, Demodulator, GfdmHipError, Modulator, Transmitter, exported_symbols,  # noqa: F401
-                   generic_family_for_testing, lib)
+                   generic_family_for_testing, lib, set_jit)

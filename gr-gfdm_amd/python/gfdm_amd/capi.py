@@ -49,6 +49,8 @@ def lib():
         "gfdm_hip_last_error": (cp, []),
         "gfdm_hip_device_count": (i32, []),
         "gfdm_hip_force_generic_family_for_testing": (i32, [i32]),
+        "gfdm_hip_set_jit": (i32, [i32]),
+        "gfdm_hip_jit_build_for_testing": (i32, [i32, i32, i32, i32]),
         "gfdm_hip_version": (cp, []),
         "gfdm_hip_modulator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
         "gfdm_hip_modulator_destroy": (i32, [vp]),
@@ -197,6 +199,12 @@ class generic_family_for_testing:
     def __exit__(self, *exc):
         lib().gfdm_hip_force_generic_family_for_testing(self._prev)
         return False
+
+
+def set_jit(enable):
+    """gfdm_hip_set_jit: run-time (hiprtc) instantiation of the row-lane kernels for shapes outside the compiled list; returns the
+    previous setting."""
+    return bool(lib().gfdm_hip_set_jit(1 if enable else 0))
 
 
 class _Kernel:

@@ -65,6 +65,16 @@ int gfdm_hip_device_count(void);
  * for shapes the tuned row-lane family serves, so that the tests can run both families on the same shape.  Returns the previous
  * setting.  Nothing else (no environment variable) changes the kernel family of a handle. */
 int gfdm_hip_force_generic_family_for_testing(int enable);
+/* Run-time instantiation of the tuned (row-lane) kernels for shapes outside the library's compiled list: a handle for a shape with
+ * a power-of-two number of subcarriers (4 .. 512), 3 .. 32 timeslots and overlap 2 .. 8 gets the kernels compiled for exactly that
+ * shape through hiprtc when it is created (1-10 s per part, four parts; the code objects are cached under $GFDM_HIP_CACHE_DIR,
+ * else $XDG_CACHE_HOME/gfdm_hip, else ~/.cache/gfdm_hip, so this happens once per shape and machine) and reports kernel_name
+ * "rowlane_jit".  Enabled by default; gfdm_hip_set_jit(0) makes such handles use the generic kernel family instead (no compile
+ * step, several times slower kernels).  Returns the previous setting.  If hiprtc is unavailable the generic family is used. */
+int gfdm_hip_set_jit(int enable);
+/* TEST HOOK: compile (or find in the disk cache) part 0..3 of the row-lane kernels for a shape through hiprtc WITHOUT loading it --
+ * needs no GPU, so the CPU-side tests can check that the embedded kernel sources build. */
+int gfdm_hip_jit_build_for_testing(int timeslots, int subcarriers, int overlap, int part);
 const char* gfdm_hip_version(void);
 
 /* ---- modulator_kernel_cc (include/gfdm/modulator_kernel_cc.h:41-51) -------------------- */

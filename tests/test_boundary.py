@@ -113,3 +113,26 @@ def test_reference_pybind_bindings_compile_unchanged():
            "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include()]
     for name in ("modulator_python.cc", "demodulator_python.cc", "preamble_channel_estimator_python.cc"):
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only"] + inc + [os.path.join(ref, name)])
+
+
+def test_row_lane_kernels_build_through_hiprtc(tmp_path, monkeypatch):
+    """Run-time instantiation (gfdm_jit.hip): the kernel headers embedded in libgfdm_hip.so compile through hiprtc for shapes outside
+    the compiled list (no GPU needed for the compile), the code object lands in the disk cache and is found there the second time;
+    shapes the row-lane layout cannot hold are refused."""
+    import time
+    import gfdm_amd
+    monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(tmp_path))
+    L = gfdm_amd.lib()
+    t0 = time.perf_counter()
+    for part in range(4):
+        assert L.gfdm_hip_jit_build_for_testing(7, 16, 2, part) == 0, L.gfdm_hip_last_error()
+    first = time.perf_counter() - t0
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert len([f for f in files if f.endswith(".hsaco")]) == 4 and len([f for f in files if f.endswith(".names")]) == 4
+    t0 = time.perf_counter()
+    for part in range(4):
+        assert L.gfdm_hip_jit_build_for_testing(7, 16, 2, part) == 0
+    assert time.perf_counter() - t0 < 0.5 * first + 0.2            # served from the cache
+    assert L.gfdm_hip_jit_build_for_testing(13, 32, 4, 1) == 0, L.gfdm_hip_last_error()      # overlap 4, IC kernels
+    for (M, K, Lp) in ((9, 96, 2), (127, 16, 2), (9, 1024, 2), (2, 16, 2), (9, 64, 1)):     # K not a power of two, M / K / L out of range
+        assert L.gfdm_hip_jit_build_for_testing(M, K, Lp, 0) != 0

@@ -30,7 +30,11 @@ def test_estimate_frame_matches_pygfdm(name):
     M, K, A = g["M"], g["K"], g["A"]
     est = gfdm_amd.ChannelEstimator(M, K, A, True, 1, g["preamble"])
     assert (est.timeslots(), est.fft_len(), est.active_subcarriers(), est.frame_len(), est.is_dc_free()) == (M, K, A, M * K, True)
-    assert est.kernel_name() == ("rowlane" if (K, M) in ((64, 9), (128, 15), (64, 5)) else "generic_lds")      # both families are exercised
+    # compiled shapes, a shape instantiated at run time, and (below) the generic family on the same inputs
+    assert est.kernel_name() == ("rowlane" if (K, M) in ((64, 9), (128, 15), (64, 5)) else "rowlane_jit" if (K, M) == (32, 3) else "generic_lds")
+    with gfdm_amd.generic_family_for_testing():
+        gen = gfdm_amd.ChannelEstimator(M, K, A, True, 1, g["preamble"])
+    assert gen.kernel_name() == "generic_lds" and rel_err(gen.estimate_frame(g["rx_preambles"]), g["pygfdm_frame_estimates"]) < TOL
     got = est.estimate_frame(g["rx_preambles"])
     assert got.shape == g["pygfdm_frame_estimates"].shape
     assert rel_err(got, g["pygfdm_frame_estimates"]) < TOL

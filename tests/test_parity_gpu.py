@@ -502,7 +502,8 @@ def test_generic_family_any_subcarrier_count(M, K, L):
     N, B = M * K, 5
     taps = get_frequency_domain_filter("rrc", 0.4, M, K, L)
     nt = R.normalize_taps(taps, M)
-    mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    with gfdm_amd.generic_family_for_testing():                  # (power-of-two K would otherwise be instantiated at run time)
+        mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
     assert mod.kernel_name() == "generic_lds"
     sym = qpsk(rng, (B, N))
     x = R.modulate(sym, nt, M, K, L)
@@ -511,8 +512,53 @@ def test_generic_family_any_subcarrier_count(M, K, L):
     xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
     assert rel_err(dem.demodulate_equalize(xe, feq), R.demodulate(xe, nt, M, K, L, feq)) < TOL
     assert rel_err(dem.demodulate(x), R.demodulate(x, nt, M, K, L)) < TOL
-    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+    with gfdm_amd.generic_family_for_testing():
+        adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
     ref, st = R.advanced_receive(xe, nt, M, K, L, np.arange(K), R.qpsk_points(), 2, f_eq=feq, kind="qpsk", return_stages=True)
     keep = guarded(st, np.arange(K), K, M)
     if keep.any():
         assert rel_err(adv.demodulate_equalize(xe, feq)[keep], ref[keep]) < TOL
+
+
+@pytest.mark.parametrize("M,K,L,alpha", [(7, 16, 2, 0.3), (13, 32, 4, 0.4), (11, 8, 2, 0.5), (27, 128, 2, 0.2), (6, 256, 2, 0.3), (28, 64, 2, 0.1), (5, 4, 8, 0.5)])
+def test_row_lane_kernels_instantiated_at_run_time(M, K, L, alpha, tmp_path, monkeypatch):
+    """Shapes outside the compiled list with a power-of-two K get the row-lane kernels instantiated through hiprtc when the handle
+    is created (gfdm_jit.hip): every mode against the oracle, the generic family on the same inputs, and the switch that turns the
+    run-time instantiation off."""
+    import gfdm_amd
+    monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(tmp_path))       # cold cache: really compile
+    rng = np.random.default_rng(31 * M + K + L)
+    taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    N, B = M * K, 37
+    smap = np.arange(K) if K < 8 else np.concatenate((np.arange(1, K // 2 - 1), np.arange(K // 2 + 1, K)))
+    mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, 2, R.qpsk_points())
+    assert (mod.kernel_name(), dem.kernel_name(), adv.kernel_name()) == ("rowlane_jit",) * 3
+    prev = gfdm_amd.set_jit(False)
+    try:
+        assert prev is True and gfdm_amd.Demodulator(M, K, L, taps).kernel_name() == "generic_lds"
+    finally:
+        gfdm_amd.set_jit(True)
+    d = np.zeros((B, K, M), complex)
+    d[:, smap, :] = qpsk(rng, (B, len(smap), M))
+    d = d.reshape(B, N)
+    x = R.modulate(d, nt, M, K, L)
+    feq = np.fft.fft(np.array([1, .5, .1j, .1 + .05j]), N)[None, :] * np.exp(0.01j * np.arange(B))[:, None]
+    xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
+    S = R.fft_filter_downsample(x, nt, M, K, L)
+    assert rel_err(mod.modulate(d), x) < TOL
+    assert rel_err(dem.fft_filter_downsample(x), S) < TOL
+    assert rel_err(dem.fft_equalize_filter_downsample(xe, feq), R.fft_filter_downsample(xe, nt, M, K, L, feq)) < TOL
+    assert rel_err(dem.demodulate(x), R.demodulate(x, nt, M, K, L)) < TOL
+    assert rel_err(dem.demodulate_equalize(xe, feq), R.demodulate(xe, nt, M, K, L, feq)) < TOL
+    for inp, eq in ((x, None), (xe, feq)):
+        ref, st = R.advanced_receive(inp, nt, M, K, L, smap, R.qpsk_points(), 2, f_eq=eq, kind="qpsk", return_stages=True)
+        keep = guarded(st, smap, K, M)
+        got = adv.demodulate(inp) if eq is None else adv.demodulate_equalize(inp, eq)
+        assert keep.sum() >= B // 2 and rel_err(got[keep], ref[keep]) < TOL
+    # frames in, demapped symbols out (load offset / gather store of the same kernels)
+    dem.configure_frames(N + 12, 5, smap, True)
+    frames = rng.standard_normal((B, N + 12)) + 1j * rng.standard_normal((B, N + 12))
+    frames[:, 5:5 + N] = xe
+    assert rel_err(dem.demodulate_frames(frames, feq), R.demap_from_resources(R.demodulate(xe, nt, M, K, L, feq), M, K, smap, True)) < TOL
