@@ -24,10 +24,13 @@
  * Stockham implementation (radix 4/2/3/5 butterflies, direct O(p^2) butterfly
  * for other primes).
  *
- * Pinning: checked against the pygfdm golden vectors in tests/golden/ and the
- * numpy restatement oracle/gfdm_ref.py (tests/test_oracle.py).  The C++
- * reference could not be built here (FFTW3f/VOLK/GNU Radio absent), so there
- * is no oracle/_ref.
+ * Pinning: checked against the pygfdm golden vectors in tests/golden/ --
+ * modulator, receiver (overlap 2), IC taps, cancel_sc_interference and the IC
+ * loop (make_golden.py, make_golden_ic.py) -- and the numpy restatement
+ * oracle/gfdm_ref.py (tests/test_oracle.py).  The C++ reference could not be
+ * built here (FFTW3f/VOLK/GNU Radio absent), so there is no oracle/_ref.
+ * gfdm_oracle_bench.c is the multi-threaded timing driver of bench.py's
+ * cpu_baseline leg.
  */
 #define _GNU_SOURCE
 #include "gfdm_oracle.h"

@@ -13,21 +13,24 @@ a leading batch axis.  Each function cites the reference lines it follows
   receiver     lib/receiver_kernel_cc.cc:56-63, 99-118, 165-192, 211-225, 274-334
   IC receiver  lib/advanced_receiver_kernel_cc.cc:56-123
 
-Pinning (see DESIGN.md "Oracle"):
-  * modulate (any overlap) and demodulate (overlap == 2) are checked against
-    golden vectors produced by the reference's own Python model `pygfdm`
-    (tests/golden/make_golden.py, run in the build container), exactly the
-    expectation the reference's C++ tests use (python/qa_python_bindings.py:254-440).
-  * cancel_sc_interference / the IC loop are pinned by the reference tests'
-    known-answer properties (genie IC -> data to 1 place, loop-back IC
-    convergence to 2 places / 1 place: python/qa_python_bindings.py:410-415,
-    python/qa_advanced_receiver_sb_cc.py:119,172).
-  * the receiver at overlap != 2 has NO reference expectation (pygfdm's
-    receiver hard-codes overlap 2, python/pygfdm/gfdm_receiver.py:54,207);
-    it is pinned only through the transpose identity with the (pinned)
-    modulator, tests/test_oracle.py::test_receiver_is_transpose_of_modulator.
-  * the C++ reference itself is unbuildable here (needs FFTW3f, VOLK and
-    GNU Radio headers, none installed) and was NOT built against stand-ins.
+Pinning (see DESIGN.md "Oracle"): every stage is checked against golden vectors produced in the build
+container by the reference's own Python model `pygfdm` (tests/golden/make_golden*.py, tests/test_oracle.py):
+  * modulate (any overlap) and demodulate (overlap == 2): gfdm_modulate_block / gfdm_demodulate_block, exactly
+    the expectation the reference's C++ tests use (python/qa_python_bindings.py:254-440);
+  * ic_filter_taps, cancel_sc_interference and the IC loop (to_td -> 5 x (QPSK decision, cancel against the
+    unchanged S, to_td)): gfdm_get_ic_f_taps, gfdm_remove_sc_interference, gfdm_transform_subcarriers_to_tdomain,
+    map_qpsk_stream (python/pygfdm/gfdm_receiver.py:91-114, utils.py:80-82; tests/golden/make_golden_ic.py),
+    for real RRC taps and for complex asymmetric taps, BASELINE configs 1-5 and the reference's IC test shapes;
+    plus the reference tests' own known answers (genie IC to 1 place, loop-back convergence:
+    python/qa_python_bindings.py:410-415, python/qa_advanced_receiver_sb_cc.py:119,172);
+  * the receiver's filter stage at overlap != 2 has NO reference expectation (pygfdm's receiver hard-codes
+    overlap 2, python/pygfdm/gfdm_receiver.py:54,207); it is pinned through the exact transpose identity with
+    the (pinned) modulator, tests/test_oracle.py::test_receiver_is_transpose_of_modulator.  The IC stage at
+    overlap 4 IS pinned by pygfdm (its functions do not depend on the overlap once S is given);
+  * gr::digital::constellation (GNU Radio, outside the reference tree): QPSK decisions agree with pygfdm's
+    map_qpsk_stream away from exact zeros; the zero -> negative-point tie rule is from GNU Radio's source;
+  * the C++ reference itself is unbuildable here (needs FFTW3f, VOLK and GNU Radio headers, none installed)
+    and was NOT built against stand-ins.
 
 All arithmetic is complex128; callers round to complex64 where they compare
 with float32 results.
