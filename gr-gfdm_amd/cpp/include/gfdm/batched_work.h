@@ -8,7 +8,7 @@
  *     lib/transmitter_cc_impl.cc:130-195           per frame: modulate once, add_frame per output port
  *     lib/channel_estimator_cc_impl.cc:88-120      per frame: estimate_frame + estimate_snr, two stream tags
  * With a GPU behind the kernel classes that loop would pay one host-to-device copy, one launch, one device-to-host copy and one
- * synchronisation PER BLOCK (bench.py: single_block_host_us, ~28 us against ~10 us for the CPU kernel).  The functions here take the
+ * synchronisation PER BLOCK (bench.py: single_block_host_us, ~17 us against ~10 us for the CPU kernel).  The functions here take the
  * scheduler's whole `noutput_items` run in one call of the kernels' *_batch methods: same pointers, same return values, same item
  * accounting as the loops above -- a wrapper's work() becomes one line.
  *

@@ -55,6 +55,11 @@ struct Plan {
     hipStream_t stream = nullptr;    // private stream for the *_host entry points
     cf* stage[3] = { nullptr, nullptr, nullptr };
     size_t stage_elems[3] = { 0, 0, 0 };
+    // small *_host calls (a GNU Radio wrapper handing over one block at a time): one pinned, GPU-mapped host buffer -- the kernel
+    // reads its input and writes its output straight across PCIe, which saves the two copy commands of the staged path
+    cf* pinned = nullptr;            // host address
+    cf* pinned_dev = nullptr;        // the same memory as the GPU sees it
+    size_t pinned_elems = 0;
     std::string kernel_name;
     const cf* d_twT = nullptr;       // [M][K] twiddles W_N^{q m}, transposed so that lane q reads them coalesced (row-lane family)
     int family = gfdm::FAMILY_GENERIC;
@@ -65,6 +70,7 @@ struct Plan {
         bool restore = (hipGetDevice(&prev) == hipSuccess);
         (void)hipSetDevice(device);
         for (auto& s : stage) if (s) (void)hipFree(s);
+        if (pinned) (void)hipHostFree(pinned);
         if (d_tables) (void)hipFree(d_tables);
         if (stream) (void)hipStreamDestroy(stream);
         if (restore) (void)hipSetDevice(prev);
@@ -210,6 +216,12 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     return GFDM_HIP_OK;
 }
 
+// *_host calls moving at most this many bytes (inputs + output) go through the pinned, GPU-mapped buffer instead of staged copies
+#ifndef GFDM_ZEROCOPY_MAX_BYTES
+#define GFDM_ZEROCOPY_MAX_BYTES (1024 * 1024)   /* measured crossover with the staged path: 1.2-1.5 MB */
+#endif
+constexpr size_t kZeroCopyMaxBytes = GFDM_ZEROCOPY_MAX_BYTES;
+
 int ensure_stage(Plan& pl, int slot, size_t elems)
 {
     if (pl.stage_elems[slot] >= elems) return GFDM_HIP_OK;
@@ -231,6 +243,31 @@ int run_host_sized(Plan& pl, float* out, size_t out_elems, const float* in0, siz
     DeviceGuard guard(pl.device);
     if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
     int rc;
+    const size_t in1_used = in1 ? in1_elems : 0;
+    if ((out_elems + in0_elems + in1_used) * sizeof(cf) <= kZeroCopyMaxBytes) {
+        // small call: through the pinned, GPU-mapped buffer (out | in0 | in1), one launch and one wait, no copy commands
+        const size_t o0 = 0, o1 = (out_elems + 15) & ~(size_t)15, o2 = o1 + ((in0_elems + 15) & ~(size_t)15), total = o2 + ((in1_used + 15) & ~(size_t)15);
+        if (pl.pinned_elems < total) {
+            if (pl.pinned) { (void)hipHostFree(pl.pinned); pl.pinned = nullptr; pl.pinned_elems = 0; }
+            const size_t want = total < 8192 ? 8192 : total;
+            if (hipHostMalloc(reinterpret_cast<void**>(&pl.pinned), want * sizeof(cf), hipHostMallocMapped) == hipSuccess &&
+                hipHostGetDevicePointer(reinterpret_cast<void**>(&pl.pinned_dev), pl.pinned, 0) == hipSuccess) {
+                pl.pinned_elems = want;
+            } else {
+                if (pl.pinned) (void)hipHostFree(pl.pinned);
+                pl.pinned = nullptr;                                  // no mapped host memory: the staged path below serves the call
+            }
+        }
+        if (pl.pinned) {
+            memcpy(pl.pinned + o1, in0, in0_elems * sizeof(cf));
+            if (in1) memcpy(pl.pinned + o2, in1, in1_elems * sizeof(cf));
+            hipError_t e = launch(pl.pinned_dev + o0, pl.pinned_dev + o1, in1 ? pl.pinned_dev + o2 : nullptr, pl.stream);
+            if (e != hipSuccess) return fail_hip(e, "kernel launch");
+            HIP_TRY(hipStreamSynchronize(pl.stream));
+            memcpy(out, pl.pinned + o0, out_elems * sizeof(cf));
+            return GFDM_HIP_OK;
+        }
+    }
     if ((rc = ensure_stage(pl, 0, out_elems)) != GFDM_HIP_OK) return rc;
     if ((rc = ensure_stage(pl, 1, in0_elems)) != GFDM_HIP_OK) return rc;
     if (in1 && (rc = ensure_stage(pl, 2, in1_elems)) != GFDM_HIP_OK) return rc;
