@@ -82,6 +82,13 @@ template <int K> struct RowShape {
 #else
     static constexpr bool RADIX16 = false;
 #endif
+    // K = 128 = 8 x 16: one radix-8 and one radix-16 pass instead of three radix-4 passes and a radix-2 pass (lds_subcarrier_fft8x16)
+#ifndef GFDM_NO_RADIX8X16
+    static constexpr bool RADIX8X16 = (K == 128);
+#else
+    static constexpr bool RADIX8X16 = false;
+#endif
+    static constexpr bool WIDE = RADIX16 || RADIX8X16;     // FftTwiddles holds the 15 (7) twiddles of the first wide pass
 };
 
 constexpr int pow4(int s) { return 1 << (2 * s); }
@@ -125,7 +132,12 @@ template <int K> struct EstTile {
 template <int K> struct FftLayout {
     static __device__ __forceinline__ int slot(int row)
     {
-        if constexpr (RowShape<K>::RADIX16) {
+        if constexpr (RowShape<K>::RADIX8X16) {
+            // row = 32 a + 8 b + c: the radix-8 pass writes rows 8 tq + u (16 lanes vary a and b), everything else touches 8 or 16
+            // consecutive rows; rotating c by 2 a keeps all of them distinct mod 32
+            const int a = (row >> 5) & 3, c = row & 7;
+            return (row & ~7) | ((c + 2 * a) & 7);
+        } else if constexpr (RowShape<K>::RADIX16) {
             // radix-16 passes: 16 neighbouring lanes touch rows tq + 16 r (reads, phase A), 16 tq + u (pass-0 writes); rotating the
             // low four row bits by the next four keeps the slots of both patterns distinct mod 32 (b64 slots, odd row stride)
             return (row & ~15) | ((row + (row >> 4)) & 15);
@@ -146,8 +158,8 @@ template <int K> struct FftLayout {
 // (next to the sample loads): loaded inside the passes, each pass would wait for a vector-memory round trip between its LDS reads
 // and writes, because loads cannot be hoisted across the ordering points.
 template <int K> struct FftTwiddles {
-    cf w[RowShape<K>::RADIX16 ? 1 : RowShape<K>::NP4][3];
-    cf w16[RowShape<K>::RADIX16 ? 15 : 1];                 // radix-16: W_K^{tq u}, u = 1 .. 15, of the first pass
+    cf w[RowShape<K>::WIDE ? 1 : RowShape<K>::NP4][3];
+    cf w16[RowShape<K>::RADIX16 ? 15 : RowShape<K>::RADIX8X16 ? 7 : 1];   // wide first pass: W_K^{tq u}, u = 1 .. 15 (radix 16) / 1 .. 7 (radix 8)
 };
 
 template <int K>
@@ -159,8 +171,13 @@ __device__ __forceinline__ void load_fft_twiddles(FftTwiddles<K>& t, int lane, c
         static_for<1, 16>([&](auto ui) { constexpr int u = decltype(ui)::value; t.w16[u - 1] = wK[(tq16 * u) & (K - 1)]; });
         return;
     }
+    if constexpr (S::RADIX8X16) {
+        const int tq8 = lane % (K / 8);
+        static_for<1, 8>([&](auto ui) { constexpr int u = decltype(ui)::value; t.w16[u - 1] = wK[(tq8 * u) & (K - 1)]; });
+        return;
+    }
     const int tq = lane % S::RG;
-    static_for<0, S::RADIX16 ? 0 : S::NP4>([&](auto si) {
+    static_for<0, S::WIDE ? 0 : S::NP4>([&](auto si) {
         constexpr int s = decltype(si)::value;
         constexpr int str = pow4(s), ms = K / str / 4;
         if constexpr (ms > 1) {
@@ -210,6 +227,57 @@ __device__ __forceinline__ void lds_subcarrier_fft16(cf* tile, int lane, const F
     });
 }
 
+// K = 128: a radix-8 pass (lane (tq, cg), tq = lane % 16: rows tq + 16 r, r < 8, of column group cg = lane / 16 -> rows 8 tq + u with
+// twiddle W_K^{tq u}) and a radix-16 pass (tq = lane % 8: rows tq + 8 r, r < 16, of column group lane / 8, read and written by the same
+// lane, natural order out).  Codelets Dft<8> and Dft<16>.
+template <int K, int M, bool INV>
+__device__ __forceinline__ void lds_subcarrier_fft8x16(cf* tile, int lane, const FftTwiddles<K>& twd)
+{
+    static_assert(K == 128, "radix 8 x radix 16");
+    using LY = FftLayout<K>;
+    {
+        constexpr int RG = K / 8, CMAX = (M + 7) / 8;
+        const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+        cf x[CMAX][8];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) static_for<0, 8>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
+        });
+        block_sync<K>();
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                Dft<8, INV>::run(x[c]);
+                static_for<0, 8>([&](auto ui) {
+                    constexpr int u = decltype(ui)::value;
+                    cf y = x[c][u];
+                    if constexpr (u > 0) y = cmul_dir<INV>(y, twd.w16[u - 1]);
+                    tile[LY::slot(8 * tq + u) * M + c0 + c] = y;
+                });
+            }
+        });
+        block_sync<K>();
+    }
+    {
+        constexpr int RG = K / 16, CMAX = (M + 15) / 16;
+        const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+        cf x[CMAX][16];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) static_for<0, 16>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
+        });
+        block_sync<K>();
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                Dft<16, INV>::run(x[c]);
+                static_for<0, 16>([&](auto ui) { constexpr int u = decltype(ui)::value; tile[(tq + RG * u) * M + c0 + c] = x[c][u]; });
+            }
+        });
+        block_sync<K>();
+    }
+}
+
 template <int K, int M, bool INV, int FIRST = 0>
 __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const FftTwiddles<K>& twd)
 {
@@ -217,6 +285,10 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
     using LY = FftLayout<K>;
     if constexpr (S::RADIX16) {
         lds_subcarrier_fft16<K, M, INV>(tile, lane, twd);
+        return;
+    }
+    if constexpr (S::RADIX8X16) {
+        lds_subcarrier_fft8x16<K, M, INV>(tile, lane, twd);
         return;
     }
     constexpr int RG = S::RG, CMAX = (M + 3) / 4;
@@ -229,7 +301,7 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
         constexpr bool last = (s == S::NP4 - 1) && !S::HAS2;      // the pass that leaves the data in natural order
         const int j = tq & (str - 1), qq = tq / str;
         cf w1, w2, w3;
-        if constexpr (ms > 1 && !S::RADIX16) { w1 = twd.w[s][0]; w2 = twd.w[s][1]; w3 = twd.w[s][2]; }
+        if constexpr (ms > 1 && !S::WIDE) { w1 = twd.w[s][0]; w2 = twd.w[s][1]; w3 = twd.w[s][2]; }
         cf* wb[4];
         static_for<0, 4>([&](auto ui) {
             constexpr int u = decltype(ui)::value;
