@@ -35,17 +35,51 @@ __device__ __forceinline__ cf cdiv(cf a, cf b)
     return make_float2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
 }
 
+// (idx / d, idx % d) for idx = start, start + step, ...: one division at the start, then increments (the generic kernels walk
+// every tile with idx = threadIdx.x + i * GT and need row / column of each element; d is a run-time value)
+struct DivStep {
+    int q, r, dq, dr, d;
+    __device__ __forceinline__ DivStep(int start, int step, int den) : d(den)
+    {
+        q = start / den; r = start - q * den;
+        dq = step / den; dr = step - dq * den;
+    }
+    __device__ __forceinline__ void next()
+    {
+        q += dq; r += dr;
+        if (r >= d) { r -= d; ++q; }
+    }
+};
+
+// The roots W_M and W_K are read once per multiply-add of the table-driven transforms: every kernel copies them from global
+// memory into LDS first (behind its tiles, at byte offset tab_off of the dynamic region) and works on a plan that points there.
+__device__ __forceinline__ DevicePlan stage_tables(const DevicePlan& p, unsigned char* smem, int tab_off)
+{
+    cf* lwM = reinterpret_cast<cf*>(smem + tab_off);
+    cf* lwK = lwM + p.M;
+    cf* lg = lwK + p.K;
+    for (int i = threadIdx.x; i < p.M; i += GT) { lwM[i] = p.wM[i]; lg[i] = p.icg[i]; }
+    for (int i = threadIdx.x; i < p.K; i += GT) lwK[i] = p.wK[i];
+    DevicePlan q = p;
+    q.wM = lwM;
+    q.wK = lwK;
+    q.icg = lg;
+    return q;                                   // the caller's first __syncthreads() publishes the tables
+}
+
 // dst[r*M + m] = scale * sum_p src[r*rs + p*ps] * W_M^{+-(p m)}      (dst may be LDS or global)
 template <bool INV>
 __device__ void row_dft(cf* dst, const cf* src, int rows, int M, int rs, int ps, const cf* __restrict__ wM, float scale)
 {
-    for (int idx = threadIdx.x; idx < rows * M; idx += GT) {
-        const int r = idx / M, m = idx - r * M;
+    DivStep ix(threadIdx.x, GT, M);
+    for (int idx = threadIdx.x; idx < rows * M; idx += GT, ix.next()) {
+        const int r = ix.q, m = ix.r;
         cf acc = make_float2(0.f, 0.f);
         int e = 0;
+        const cf* row = src + r * rs;
         for (int p = 0; p < M; ++p) {
             const cf w = wM[e];
-            const cf v = src[r * rs + p * ps];
+            const cf v = row[p * ps];
             acc = INV ? cfmaj(v, w, acc) : cfma(v, w, acc);
             e += m;
             if (e >= M) e -= M;
@@ -81,9 +115,10 @@ __device__ cf* col_fft(cf* a, cf* b, const DevicePlan& p)
         const int r = next_radix(n), m = n / r;
         const int rstep = K / r;                                  // W_r^1 = wK[K / r]
         const int total = m * s * M;                              // (butterfly, column) pairs of this pass
-        for (int idx = threadIdx.x; idx < total; idx += GT) {
-            const int bf = idx / M, col = idx - bf * M;
-            const int q = bf % s, pp = bf / s;
+        DivStep bx(threadIdx.x, GT, M);
+        for (int idx = threadIdx.x; idx < total; idx += GT, bx.next()) {
+            const int bf = bx.q, col = bx.r;
+            const int pp = (s == 1) ? bf : bf / s, q = bf - pp * s;
             const cf* xin = x + (q + s * pp) * M + col;           // element k at xin[s m k M]
             cf* yout = y + (q + s * r * pp) * M + col;            // element j at yout[s j M]
             const int in_step = s * m * M, out_step = s * M;
@@ -165,10 +200,11 @@ __device__ __forceinline__ cf decide(cf x, const IcParams& ic)
 __device__ void cancel_rows(cf* dst, const cf* td, const cf* fd, const DevicePlan& p)
 {
     const int M = p.M, K = p.K;
-    for (int idx = threadIdx.x; idx < p.N; idx += GT) {
-        const int k = idx / M, m = idx - k * M;
-        const cf* prev = td + ((k - 1 + K) % K) * M;
-        const cf* next = td + ((k + 1) % K) * M;
+    DivStep ix(threadIdx.x, GT, M);
+    for (int idx = threadIdx.x; idx < p.N; idx += GT, ix.next()) {
+        const int k = ix.q, m = ix.r;
+        const cf* prev = td + (k == 0 ? K - 1 : k - 1) * M;
+        const cf* next = td + (k == K - 1 ? 0 : k + 1) * M;
         cf acc = make_float2(0.f, 0.f);
         int e = 0;
         for (int q = 0; q < M; ++q) {
@@ -192,9 +228,10 @@ __device__ void emit_demapped(cf* o, const cf* tile, const RxIo& io, int K, int 
     }
 }
 
-__global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan p, TxParams tx, cf* __restrict__ out, const cf* __restrict__ in)
+__global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan pg, TxParams tx, int tab_off, cf* __restrict__ out, const cf* __restrict__ in)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevicePlan p = stage_tables(pg, smem, tab_off);
     cf* t0 = reinterpret_cast<cf*>(smem);
     cf* t1 = t0 + p.N;
     const int M = p.M, K = p.K, L = p.L, N = p.N;
@@ -211,8 +248,9 @@ __global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan p, TxParams 
     __syncthreads();
     // gather form of the filter + overlap-add scatter (:116-132):
     //   Y[j][m] = sum_i D[(j - i + L/2) mod K][m] * taps[((i + L/2) % L) M + m],  m < part_len
-    for (int idx = threadIdx.x; idx < N; idx += GT) {
-        const int j = idx / M, m = idx - j * M;
+    DivStep jx(threadIdx.x, GT, M);
+    for (int idx = threadIdx.x; idx < N; idx += GT, jx.next()) {
+        const int j = jx.q, m = jx.r;
         cf acc = make_float2(0.f, 0.f);
         if (m < p.part_len) {
             for (int i = 0; i < L; ++i) {
@@ -225,15 +263,16 @@ __global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan p, TxParams 
     __syncthreads();
     cf* z = col_fft<true>(t1, t0, p);                              // K-point inverse over j
     cf* u = (z == t1) ? t0 : t1;
-    for (int idx = threadIdx.x; idx < N; idx += GT) {              // twiddle conj(W_N^{q m})
-        const int q = idx / M, m = idx - q * M;
-        u[idx] = cmulj(z[idx], p.wN[q * m]);
+    DivStep qx(threadIdx.x, GT, M);
+    for (int idx = threadIdx.x; idx < N; idx += GT, qx.next()) {   // twiddle conj(W_N^{q m})
+        u[idx] = cmulj(z[idx], p.wN[qx.q * qx.r]);
     }
     __syncthreads();
     // x[K p + q] = (1/N) sum_m u[q][m] conj(W_M^{p m});  q fastest so the global store is coalesced   :137-140
     const float scale = 1.f / (float)N;
-    for (int idx = threadIdx.x; idx < N; idx += GT) {
-        const int pp = idx / K, q = idx - pp * K;
+    DivStep px(threadIdx.x, GT, K);
+    for (int idx = threadIdx.x; idx < N; idx += GT, px.next()) {
+        const int pp = px.q, q = px.r;
         cf acc = make_float2(0.f, 0.f);
         int e = 0;
         for (int m = 0; m < M; ++m) {
@@ -256,10 +295,11 @@ __global__ __launch_bounds__(GT) void k_add_frame(DevicePlan p, TxParams tx, con
     tx_store_preamble(tx, blockIdx.x, threadIdx.x, GT);
 }
 
-__global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams ic, EstPlan est, int eq_source, int ntiles, int mode, int s_in_global,
-                                                        cf* __restrict__ out, const cf* __restrict__ in, const cf* __restrict__ f_eq)
+__global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams ic, EstPlan est, int eq_source, int ntiles, int mode, int s_in_global,
+                                                        int tab_off, cf* __restrict__ out, const cf* __restrict__ in, const cf* __restrict__ f_eq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevicePlan p = stage_tables(pg, smem, tab_off);
     float* red = reinterpret_cast<float*>(smem);
     cf* t0 = reinterpret_cast<cf*>(smem + RED_BYTES);
     cf* t1 = t0 + p.N;
@@ -281,8 +321,9 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams i
     for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
     __syncthreads();
     // A[q][m] = W_N^{q m} * sum_p x[K p + q] W_M^{p m}
-    for (int idx = threadIdx.x; idx < N; idx += GT) {
-        const int q = idx / M, m = idx - q * M;
+    DivStep ax(threadIdx.x, GT, M);
+    for (int idx = threadIdx.x; idx < N; idx += GT, ax.next()) {
+        const int q = ax.q, m = ax.r;
         cf acc = make_float2(0.f, 0.f);
         int e = 0;
         for (int pp = 0; pp < M; ++pp) {
@@ -304,11 +345,17 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams i
     }
     // S[k][m] = sum_i taps[((i + L/2) % L) M + m] * X[((k + i + K - L/2) % K) M + m]                    :165-192
     cf* Sdst = (mode == RX_FD) ? o : U;
-    for (int idx = threadIdx.x; idx < N; idx += GT) {
-        const int k = idx / M, m = idx - k * M;
+    DivStep fx(threadIdx.x, GT, M);
+    for (int idx = threadIdx.x; idx < N; idx += GT, fx.next()) {
+        const int k = fx.q, m = fx.r;
         cf acc = make_float2(0.f, 0.f);
-        for (int i = 0; i < L; ++i)
-            acc = cfma(p.taps[((i + L / 2) % L) * M + m], X[((k + i + K - L / 2) % K) * M + m], acc);
+        int row = k - L / 2, part = L / 2;                         // row (k + i - L/2) mod K, tap part (i + L/2) mod L
+        if (row < 0) row += K;
+        for (int i = 0; i < L; ++i) {
+            acc = cfma(p.taps[part * M + m], X[row * M + m], acc);
+            if (++row == K) row = 0;
+            if (++part == L) part = 0;
+        }
         Sdst[idx] = acc;
     }
     if (mode == RX_FD) return;
@@ -324,15 +371,20 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams i
         }
         return;
     }
+    // One cancellation round of the reference is  d_new = IDFT_M(S - ic (.) DFT_M(nb)) / M  with nb = dec_{k-1} + dec_{k+1}
+    // (receiver_kernel_cc.cc:274-299 + :211-225).  Both transforms are linear, so  d_new = d0 - g (*) nb  with d0 = IDFT_M(S) / M
+    // and the M-tap circular kernel g = IDFT_M(ic) / M (p.icg): one table-driven pass per round instead of two, S is not needed
+    // again (a rotation of S by the phase compensation is the same rotation of d0).
     cf* D = X;
     row_dft<true>(D, U, K, M, M, 1, p.wM, invM);
-    cf* S = U;
+    __syncthreads();
+    cf* D0 = U;
     cf* V = t2;
-    if (s_in_global) {                                            // third tile does not fit: park S in the output block
-        for (int idx = threadIdx.x; idx < N; idx += GT) o[idx] = U[idx];
-        S = o;
+    if (s_in_global) {                                            // third tile does not fit: d0 lives in the output block
+        D0 = o;
         V = U;
     }
+    for (int idx = threadIdx.x; idx < N; idx += GT) D0[idx] = D[idx];
     __syncthreads();
     for (int j = 0; j < ic.ic_iter; ++j) {                        // perform_ic_iterations            adv:56-76
         if (ic.do_phase_compensation > 0 && j == 0) {              // calculate_phase_offset           adv:78-91
@@ -353,32 +405,65 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan p, IcParams i
             float sn, cs;
             sincosf(phi, &sn, &cs);
             const cf rot = make_float2(cs, sn);
-            for (int idx = threadIdx.x; idx < N; idx += GT) S[idx] = cmul(S[idx], rot);   // in place, persists  adv:63-70
+            for (int idx = threadIdx.x; idx < N; idx += GT) D0[idx] = cmul(D0[idx], rot);   // rotating S rotates d0; persists  adv:63-70
             __syncthreads();
         }
-        for (int idx = threadIdx.x; idx < N; idx += GT)           // map_symbols_to_constellation_points  adv:109-123
-            D[idx] = ic.active[idx / M] ? decide(D[idx], ic) : make_float2(0.f, 0.f);
+        {
+            DivStep dx(threadIdx.x, GT, M);
+            for (int idx = threadIdx.x; idx < N; idx += GT, dx.next())   // map_symbols_to_constellation_points  adv:109-123
+                D[idx] = ic.active[dx.q] ? decide(D[idx], ic) : make_float2(0.f, 0.f);
+        }
         __syncthreads();
-        cancel_rows(V, D, S, p);
-        __syncthreads();
-        if (j == ic.ic_iter - 1) {
-            if (!demap) {
-                row_dft<true>(o, V, K, M, M, 1, p.wM, invM);
-            } else {
-                row_dft<true>(D, V, K, M, M, 1, p.wM, invM);
-                __syncthreads();
-                emit_demapped(o, D, ic.io, K, M);
+        {                                                         // nb = dec_{k-1} + dec_{k+1} (wraps mod K)  rx:279-284
+            DivStep nx(threadIdx.x, GT, M);
+            for (int idx = threadIdx.x; idx < N; idx += GT, nx.next()) {
+                const int k = nx.q, pp = nx.r;
+                V[idx] = cadd(D[(k == 0 ? K - 1 : k - 1) * M + pp], D[(k == K - 1 ? 0 : k + 1) * M + pp]);
             }
-        } else {
-            row_dft<true>(D, V, K, M, M, 1, p.wM, invM);
-            __syncthreads();
         }
+        __syncthreads();
+        const bool last = (j == ic.ic_iter - 1);
+        cf* dst = (last && !demap) ? o : D;                        // the decisions are spent: the new symbols replace them
+        DivStep cx(threadIdx.x, GT, M);
+        for (int idx = threadIdx.x; idx < N; idx += GT, cx.next()) {
+            const int pp = cx.r;
+            const cf* nb = V + cx.q * M;
+            cf acc = D0[idx];
+            if (p.ic_real_sym) {                                   // g real and even: g_r (nb[p - r] + nb[p + r])
+                const float g0 = p.icg[0].x;
+                acc = make_float2(acc.x - g0 * nb[pp].x, acc.y - g0 * nb[pp].y);
+                int lo = pp, hi = pp;
+                const int H = (M - 1) / 2;
+                for (int r = 1; r <= H; ++r) {
+                    if (--lo < 0) lo = M - 1;
+                    if (++hi == M) hi = 0;
+                    const float g = p.icg[r].x;
+                    acc = make_float2(acc.x - g * (nb[lo].x + nb[hi].x), acc.y - g * (nb[lo].y + nb[hi].y));
+                }
+                if ((M & 1) == 0) {                                // the middle tap of an even length
+                    if (--lo < 0) lo = M - 1;
+                    const float g = p.icg[M / 2].x;
+                    acc = make_float2(acc.x - g * nb[lo].x, acc.y - g * nb[lo].y);
+                }
+            } else {
+                int src = pp;                                     // (pp - r) mod M
+                for (int r = 0; r < M; ++r) {
+                    const cf g = p.icg[r], x = nb[src];
+                    acc = make_float2(acc.x - g.x * x.x + g.y * x.y, acc.y - g.x * x.y - g.y * x.x);
+                    if (--src < 0) src = M - 1;
+                }
+            }
+            dst[idx] = acc;
+        }
+        __syncthreads();
+        if (last && demap) emit_demapped(o, D, ic.io, K, M);
     }
 }
 
-__global__ __launch_bounds__(GT) void k_generic_to_td(DevicePlan p, cf* __restrict__ out, const cf* __restrict__ in)
+__global__ __launch_bounds__(GT) void k_generic_to_td(DevicePlan pg, int tab_off, cf* __restrict__ out, const cf* __restrict__ in)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevicePlan p = stage_tables(pg, smem, tab_off);
     cf* t0 = reinterpret_cast<cf*>(smem);
     const cf* x = in + (int64_t)blockIdx.x * p.N;
     for (int idx = threadIdx.x; idx < p.N; idx += GT) t0[idx] = x[idx];
@@ -386,10 +471,11 @@ __global__ __launch_bounds__(GT) void k_generic_to_td(DevicePlan p, cf* __restri
     row_dft<true>(out + (int64_t)blockIdx.x * p.N, t0, p.K, p.M, p.M, 1, p.wM, 1.f / (float)p.M);
 }
 
-__global__ __launch_bounds__(GT) void k_generic_cancel(DevicePlan p, cf* __restrict__ out, const cf* __restrict__ td,
+__global__ __launch_bounds__(GT) void k_generic_cancel(DevicePlan pg, int tab_off, cf* __restrict__ out, const cf* __restrict__ td,
                                                        const cf* __restrict__ fd)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevicePlan p = stage_tables(pg, smem, tab_off);
     cf* t0 = reinterpret_cast<cf*>(smem);
     const cf* x = td + (int64_t)blockIdx.x * p.N;
     for (int idx = threadIdx.x; idx < p.N; idx += GT) t0[idx] = x[idx];
@@ -506,16 +592,18 @@ hipError_t allow_lds(KernelT kernel, size_t bytes)
 }  // namespace
 
 size_t generic_lds_bytes(int N, int ntiles) { return (size_t)ntiles * (size_t)N * sizeof(cf) + RED_BYTES; }
+// ... plus the W_M and W_K tables behind everything else
+static size_t table_bytes(const DevicePlan& p) { return (((size_t)(2 * p.M + p.K) * sizeof(cf)) + 15) & ~(size_t)15; }
 
-bool generic_supports(int N, bool) { return generic_lds_bytes(N, 2) <= LDS_MAX; }
+bool generic_supports(int M, int K, bool) { return generic_lds_bytes(M * K, 2) + (size_t)(2 * M + K + 2) * sizeof(cf) <= LDS_MAX; }
 
 hipError_t launch_generic_modulate(const DevicePlan& p, const TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    const size_t lds = generic_lds_bytes(p.N, 2);
+    const size_t tab = generic_lds_bytes(p.N, 2), lds = tab + table_bytes(p);
     hipError_t e = allow_lds(k_generic_modulate, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_generic_modulate, dim3((unsigned)nblocks), dim3(GT), lds, s, p, tx, out, in);
+    hipLaunchKernelGGL(k_generic_modulate, dim3((unsigned)nblocks), dim3(GT), lds, s, p, tx, (int)tab, out, in);
     return hipGetLastError();
 }
 
@@ -535,36 +623,36 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const
     const size_t extra = est ? (size_t)(2 * p.K + 2) * sizeof(cf) : 0;     // K-bin estimate + smoothed estimate
     int ntiles = 2, s_in_global = 0;
     if (mode == RX_IC && ic.ic_iter > 0) {
-        if (generic_lds_bytes(p.N, 3) + extra <= LDS_MAX) ntiles = 3; else s_in_global = 1;
+        if (generic_lds_bytes(p.N, 3) + extra + table_bytes(p) <= LDS_MAX) ntiles = 3; else s_in_global = 1;
     }
     if (s_in_global && ic.io.demap) return hipErrorInvalidConfiguration;   // the demapped output block is too small to park S in
-    const size_t lds = generic_lds_bytes(p.N, ntiles) + extra;
+    const size_t tab = (generic_lds_bytes(p.N, ntiles) + extra + 15) & ~(size_t)15, lds = tab + table_bytes(p);
     if (lds > LDS_MAX) return hipErrorInvalidConfiguration;
     hipError_t e = allow_lds(k_generic_receive, lds);
     if (e != hipSuccess) return e;
     static const EstPlan kNoEst = {};
     hipLaunchKernelGGL(k_generic_receive, dim3((unsigned)nblocks), dim3(GT), lds, s, p, ic, est ? *est : kNoEst, eq_source, ntiles, mode, s_in_global,
-                       out, in, f_eq);
+                       (int)tab, out, in, f_eq);
     return hipGetLastError();
 }
 
 hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    const size_t lds = generic_lds_bytes(p.N, 1);
+    const size_t tab = generic_lds_bytes(p.N, 1), lds = tab + table_bytes(p);
     hipError_t e = allow_lds(k_generic_to_td, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_generic_to_td, dim3((unsigned)nblocks), dim3(GT), lds, s, p, out, in);
+    hipLaunchKernelGGL(k_generic_to_td, dim3((unsigned)nblocks), dim3(GT), lds, s, p, (int)tab, out, in);
     return hipGetLastError();
 }
 
 hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, const cf* fd, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    const size_t lds = generic_lds_bytes(p.N, 1);
+    const size_t tab = generic_lds_bytes(p.N, 1), lds = tab + table_bytes(p);
     hipError_t e = allow_lds(k_generic_cancel, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_generic_cancel, dim3((unsigned)nblocks), dim3(GT), lds, s, p, out, td, fd);
+    hipLaunchKernelGGL(k_generic_cancel, dim3((unsigned)nblocks), dim3(GT), lds, s, p, (int)tab, out, td, fd);
     return hipGetLastError();
 }
 

@@ -121,7 +121,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GFDM_HIP_ENODEV, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(GFDM_HIP_ENODEV, "HIP device ordinal out of range");
     const int N = M * K;
-    if (!gfdm::generic_supports(N, false)) return fail(GFDM_HIP_EUNSUPPORTED, "block (timeslots*subcarriers) does not fit LDS");
+    if (!gfdm::generic_supports(M, K, false)) return fail(GFDM_HIP_EUNSUPPORTED, "block (timeslots*subcarriers) does not fit LDS");
 
     pl.device = device;
     // energy |sum t conj(t)|, factor formed in double and cast (lib/modulator_kernel_cc.cc:75-85)

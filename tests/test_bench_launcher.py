@@ -60,3 +60,20 @@ def test_bench_runs_under_an_external_torchrun_environment():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["shards"] == [[0, 5], [5, 5]]
+
+
+def test_roofline_traffic_comes_from_the_committed_pmc_summary():
+    """bench.py's `roofline.traffic` is read from the newest profiles/rNN/pmc_hbm_traffic_summary.csv (FETCH_SIZE x 2 + WRITE_SIZE
+    per launch), never hard-coded: a row exists for the default configuration's kernels at its batch, the figure is within a few
+    per cent of the algorithmic bytes, and an unprofiled batch gives None."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for kernel, bytes_per_block in (("k_row_modulate<64, 9, 2, 0>", 16 * 576), ("k_row_receive<64, 9, 2, 1, 0, false>", 16 * 576),
+                                    ("k_row_receive<64, 9, 2, 2, 1, true>", 24 * 576)):
+        tr = bench.pmc_traffic(kernel, 4096)
+        assert tr is not None and tr["source"].startswith("profiles/r")
+        assert 1.0 <= tr["bytes"] / (bytes_per_block * 4096) < 1.05
+    assert bench.pmc_traffic("k_row_receive<64, 9, 2, 1, 0, false>", 4097) is None
+    assert set(bench.CONFIGS) == {"cfg2", "cfg3", "cfg4", "cfg5"} and bench.CONFIGS["cfg4"]["total"] == bench.CONFIGS["cfg5"]["total"] == 65536
