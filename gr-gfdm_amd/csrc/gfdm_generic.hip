@@ -595,7 +595,8 @@ size_t generic_lds_bytes(int N, int ntiles) { return (size_t)ntiles * (size_t)N 
 // ... plus the W_M and W_K tables behind everything else
 static size_t table_bytes(const DevicePlan& p) { return (((size_t)(2 * p.M + p.K) * sizeof(cf)) + 15) & ~(size_t)15; }
 
-bool generic_supports(int M, int K, bool) { return generic_lds_bytes(M * K, 2) + (size_t)(2 * M + K + 2) * sizeof(cf) <= LDS_MAX; }
+// one_tile: only the single-tile kernels (to_td, cancel) have to fit
+bool generic_supports(int M, int K, bool one_tile) { return generic_lds_bytes(M * K, one_tile ? 1 : 2) + (size_t)(2 * M + K + 2) * sizeof(cf) <= LDS_MAX; }
 
 hipError_t launch_generic_modulate(const DevicePlan& p, const TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {

@@ -121,7 +121,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GFDM_HIP_ENODEV, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(GFDM_HIP_ENODEV, "HIP device ordinal out of range");
     const int N = M * K;
-    if (!gfdm::generic_supports(M, K, false)) return fail(GFDM_HIP_EUNSUPPORTED, "block (timeslots*subcarriers) does not fit LDS");
+    // (whether the block fits the kernels' LDS tiles is checked once the kernel family is known, below)
 
     pl.device = device;
     // energy |sum t conj(t)|, factor formed in double and cast (lib/modulator_kernel_cc.cc:75-85)
@@ -213,6 +213,9 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
         }
     }
     pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : pl.family == gfdm::FAMILY_ROWLANE_JIT ? "rowlane_jit" : "generic_lds";
+    // the generic family holds two tiles of the block in LDS; handles on the row-lane families only use it for the stand-alone
+    // transform_subcarriers_to_td / cancel_sc_interference entry points (one tile)
+    if (!gfdm::generic_supports(M, K, pl.family != gfdm::FAMILY_GENERIC)) return fail(GFDM_HIP_EUNSUPPORTED, "block (timeslots*subcarriers) does not fit LDS");
     return GFDM_HIP_OK;
 }
 

@@ -75,7 +75,7 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const
                                   int64_t nblocks, hipStream_t s);
 hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
 hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, const cf* fd, int64_t nblocks, hipStream_t s);
-bool generic_supports(int M, int K, bool ic);
+bool generic_supports(int M, int K, bool one_tile);
 
 // ---- row-lane family (gfdm_rowlane_impl.h, dispatch in gfdm_rowlane.hip): one lane per subcarrier row, in-place radix-4 passes ----
 bool rowlane_supports(int M, int K, int L);
