@@ -56,13 +56,25 @@ __device__ __forceinline__ cf tx_window(const TxParams& t, int f, int N, cf x)
 // time sample n of block blk: body position plus, where it applies, its copy in the cyclic prefix / suffix, every port
 __device__ __forceinline__ void tx_store_sample(const TxParams& t, int64_t blk, int N, int n, cf x)
 {
-    for (int port = 0; port < t.nports; ++port) {
-        cf* o = t.outs[port] + blk * (int64_t)t.F + t.plen;
-        const int s = t.shifts[port];
+    // one port: non-temporal stores like the other kernels (15.2 vs 17.4 us per 4096 frames); several ports: plain stores -- the
+    // frames of the ports are not line-aligned, a wave writes many partial lines, and streaming them was slower (4 ports: 40 vs 35 us
+    // per 4096 frames, 482 vs 468 us per 65 536)
+    if (t.nports == 1) {
+        cf* o = t.outs[0] + blk * (int64_t)t.F + t.plen;
+        const int s = t.shifts[0];
         const int scp = t.cp + s, scs = t.cs - s;
         dft::st_stream(o, scp + n, tx_window(t, scp + n, N, x));
         if (n >= N - scp) dft::st_stream(o, n - (N - scp), tx_window(t, n - (N - scp), N, x));
         if (n < scs) dft::st_stream(o, scp + N + n, tx_window(t, scp + N + n, N, x));
+        return;
+    }
+    for (int port = 0; port < t.nports; ++port) {
+        cf* o = t.outs[port] + blk * (int64_t)t.F + t.plen;
+        const int s = t.shifts[port];
+        const int scp = t.cp + s, scs = t.cs - s;
+        o[scp + n] = tx_window(t, scp + n, N, x);
+        if (n >= N - scp) o[n - (N - scp)] = tx_window(t, n - (N - scp), N, x);
+        if (n < scs) o[scp + N + n] = tx_window(t, scp + N + n, N, x);
     }
 }
 
@@ -72,7 +84,8 @@ __device__ __forceinline__ void tx_store_preamble(const TxParams& t, int64_t blk
     for (int port = 0; port < t.nports; ++port) {
         cf* o = t.outs[port] + blk * (int64_t)t.F;
         const cf* pre = t.preambles + (int64_t)port * t.plen;
-        for (int j = first; j < t.plen; j += step) dft::st_stream(o, j, pre[j]);
+        if (t.nports == 1) { for (int j = first; j < t.plen; j += step) dft::st_stream(o, j, pre[j]); }
+        else { for (int j = first; j < t.plen; j += step) o[j] = pre[j]; }
     }
 }
 
