@@ -1,17 +1,19 @@
 // "Row-lane" HIP kernel family for gfx950: one lane per subcarrier row, one GFDM block per K lanes.
 //
 // Why this layout: the benchmark batch (4096 blocks of K = 64, M = 9) is only 2.4 M symbols.  Spread over 256 CUs x 4 SIMDs
-// that is four blocks per SIMD, so a layout that packs several blocks into one wavefront (gfdm_fast.hip: 4 rows per lane)
-// leaves one wavefront per SIMD and the launch runs at the latency of a single wave.  Here a block occupies K lanes (a whole
+// that is four blocks per SIMD, so a layout that packs several blocks into one wavefront (e.g. four rows per lane: built and
+// measured in round 1, 17 vs 11 us) leaves one wavefront per SIMD and the launch runs at the latency of a single wave.  Here a block occupies K lanes (a whole
 // wavefront at K = 64; two at K = 128; four at K = 256): 4096 blocks become 4096 waves = 16 per CU.
 //
 // Decomposition (n = K p + q, f = M j + m):  X[M j + m] = sum_q W_K^{q j} W_N^{q m} (sum_p x[K p + q] W_M^{p m})
 //   phase A  lane q: loads x[K p + q] (a 512-byte contiguous segment per wave instruction), M-point DFT codelet
 //            (gfdm_dft.h), twiddle W_N^{q m} from a [M][K] table (coalesced), row -> the block's single LDS tile
-//   phase B  K-point FFT over q for all M columns: radix-4 Stockham passes IN PLACE in the tile.  Lane (tq, cg) owns the four
-//            rows tq + (K/4) r of column group cg (ceil(M/4) columns): every pass reads exactly those rows, so addresses are
-//            base + immediates.  For K = 64 the rows sit at a Latin-cube slot permutation during the passes (FftLayout) so
-//            that no pass access has an LDS bank conflict; the last pass writes natural order.
+//   phase B  K-point FFT over q for all M columns: Stockham passes IN PLACE in the tile, as few and as wide as the lane count
+//            allows -- K = 64: radix 4 straight from the registers (lane-row transposes) + ONE radix-16 pass; K = 128: radix 8 +
+//            radix 16; K = 256: radix 16 + radix 16; otherwise radix-4 passes (+ one radix-2).  Lane (tq, cg) owns the rows
+//            tq + (K / R) r of column group cg: every pass reads exactly those rows, so addresses are base + immediates.  During
+//            the passes the rows sit at a slot permutation (FftLayout) chosen so that no pass access has an LDS bank conflict;
+//            the last pass writes natural order.
 //   phase C  one-tap equaliser X[f] /= f_eq[f] in linear order on the tile (f_eq requested after phase A, coalesced)
 //   phase D  lane k: L-tap filter + fold over rows k - L/2 .. k + L/2 - 1 (+wrap), 1/M folded in, M-point inverse DFT
 //   IC       d_new = d0 - g (*) (dec_{k-1} + dec_{k+1}) with the M-tap circular kernel g = IDFT_M(ic)/M; for K = 64 the
@@ -19,8 +21,9 @@
 //   output   row -> tile, linear read, coalesced store
 // Blocks of K <= 64 lanes live inside one wavefront: their LDS accesses are ordered by the wave's program order, so they
 // are packed four waves to a workgroup and never wait on s_barrier (block_sync).
-// HBM traffic: x (+ f_eq) in, out out; nothing else leaves the CU.  The modulator is the transposed flow; with TXMODE the
-// resource mapper becomes its load stage and cyclic prefix / ramp / preamble its store stage (gfdm_tx.h).
+// HBM traffic: x (+ f_eq) in, out out (streamed: non-temporal loads and stores, gfdm_dft.h); nothing else leaves the CU.
+// The modulator is the transposed flow; with TXMODE the resource mapper becomes its load stage and cyclic prefix / ramp / preamble
+// its store stage (gfdm_tx.h).
 //
 // Algorithm restated from gr-gfdm: lib/modulator_kernel_cc.cc:98-141, lib/receiver_kernel_cc.cc:165-334,
 // lib/advanced_receiver_kernel_cc.cc:56-123, lib/transmitter_kernel.cc:78-107.
