@@ -78,7 +78,7 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 for the strong-scaled cfg4 / cfg5)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; 3 for cfg4 / cfg5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; 10 for cfg4 / cfg5)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--batch", type=int, default=None, help="override: blocks per step and per GPU (weak configs) or in total (strong configs)")
     ap.add_argument("--ring-mib", type=int, default=2048, help="total footprint of the buffer ring per path")
@@ -96,7 +96,7 @@ def parse(argv=None):
     if a.steps is None:
         a.steps = 20 if strong else 200
     if a.warmup is None:
-        a.warmup = 3 if strong else 20
+        a.warmup = 10 if strong else 20
     return a
 
 
