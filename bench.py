@@ -28,8 +28,8 @@ Beside the headline the JSON line carries
                   kernel and batch); `copy_ceiling_GBps` = a plain device copy of the same byte count timed the same way
   roofline_kernels  the same figures for every kernel of the step (cfg2: modulate and demodulate)
   sustained       the headline loop again for >= 2 s (the default 200 steps are a ~4 ms burst; boxes boost for short bursts)
-  single_block_host_us   one generic_work(out, in) with HOST pointers through the pybind11 drop-in class (H2D + kernel + D2H +
-                  sync): what an unchanged GNU Radio wrapper pays per block, beside the CPU port's per-block time
+  single_block_host_us   one generic_work(out, in) with HOST pointers through the pybind11 drop-in class (host copy into the pinned
+                  GPU-mapped buffer + kernel + wait): what an unchanged GNU Radio wrapper pays per block, beside the CPU port's time
   cpu_baseline    the plain-C oracle ("port" of the reference algorithm) on this host: pinned pthreads, one kernel object per
                   thread (oracle/gfdm_oracle_bench.c), all CPUs this process may run on; single thread beside it
   paths / large_batch   (N = 1, cfg2 / cfg3 only) every receiver variant and the modulator alone on the stream, and the same
@@ -311,7 +311,7 @@ def cpu_baseline(cfg, taps, seconds):
 
 def single_block_host(cfg, taps, reps=300):
     """One block through the literal drop-in path: gfdm_python.Demodulator.demodulate(ndarray) = receiver_kernel_cc::generic_work
-    with host pointers (H2D copy, kernel, D2H copy, stream sync) -- what gr-gfdm's unchanged wrappers call once per block
+    with host pointers (small calls: pinned GPU-mapped buffer, kernel, stream sync) -- what gr-gfdm's unchanged wrappers call once per block
     (lib/simple_receiver_cc_impl.cc:70-74)."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "gr-gfdm_amd", "lib"))
