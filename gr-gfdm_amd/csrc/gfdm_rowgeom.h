@@ -12,7 +12,24 @@
 namespace gfdm {
 namespace rowgeom {
 
-constexpr int wg(int K) { return K >= 128 ? K : GFDM_ROW_WG; }               // threads per workgroup
+// Subcarrier counts the family covers: powers of two 4 .. 512 (radix-4 / wide passes, gfdm_rowlane_impl.h) and any other
+// K = R0 * R1 <= 256 with both factors <= 16 (two Stockham passes with the codelets Dft<R0>, Dft<R1>; R0 = 1: a single pass).
+constexpr bool pow2(int K) { return K > 0 && (K & (K - 1)) == 0; }
+constexpr int mixed_r1(int K)                                                // radix of the LAST pass: the largest divisor <= 16
+{
+    int r = 1;
+    for (int d = 2; d <= 16 && d <= K; ++d)
+        if (K % d == 0) r = d;
+    return r;
+}
+constexpr int mixed_r0(int K) { return K / mixed_r1(K); }
+constexpr bool mixed(int K) { return !pow2(K) && K >= 3 && K <= 256 && mixed_r0(K) <= 16; }
+constexpr bool supported(int K) { return (pow2(K) && K >= 4 && K <= 512) || mixed(K); }
+
+// threads per workgroup: whole blocks only (a block never straddles two workgroups)
+constexpr int wg(int K) { return K >= 128 ? K : pow2(K) ? GFDM_ROW_WG : (GFDM_ROW_WG / K) * K; }
+// blocks of K lanes that sit inside ONE wavefront are ordered by the wave's program order; others need the workgroup barrier
+constexpr bool wave_local(int K) { return K <= 64 && 64 % K == 0; }
 constexpr int bpw(int K) { return wg(K) / K; }                               // blocks per workgroup
 constexpr int tile_stride(int K, int M) { return K * M + (bpw(K) > 1 ? 16 : 0); }   // complex elements between the tiles of a workgroup
 constexpr size_t lds_bytes(int K, int M) { return (size_t)bpw(K) * (size_t)tile_stride(K, M) * 8 + 64; }

@@ -16,7 +16,8 @@
     X(128, 15, 2)          \
     X(128, 21, 2)          \
     X(4, 16, 2)            \
-    X(4, 8, 2)
+    X(4, 8, 2)             \
+    X(96, 25, 2)
 
 namespace gfdm {
 

@@ -70,8 +70,11 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #endif
 
 template <int K> struct RowShape {
-    static constexpr int log2K = (K == 4) ? 2 : (K == 8) ? 3 : (K == 16) ? 4 : (K == 32) ? 5 : (K == 64) ? 6 : (K == 128) ? 7 : (K == 256) ? 8 : (K == 512) ? 9 : -1;
-    static_assert(log2K > 0, "row-lane family supports K = 4 .. 512, power of two");
+    static_assert(rowgeom::supported(K), "row-lane family: K a power of two 4 .. 512, or K = R0 * R1 <= 256 with both factors <= 16");
+    // K not a power of two: two Stockham passes of radix R0 and R1 (R0 = 1: one pass), lds_subcarrier_fft2
+    static constexpr bool MIXED = rowgeom::mixed(K);
+    static constexpr int R0 = MIXED ? rowgeom::mixed_r0(K) : 1, R1 = MIXED ? rowgeom::mixed_r1(K) : 1;
+    static constexpr int log2K = (K == 4) ? 2 : (K == 8) ? 3 : (K == 16) ? 4 : (K == 32) ? 5 : (K == 64) ? 6 : (K == 128) ? 7 : (K == 256) ? 8 : (K == 512) ? 9 : 0;
     static constexpr int NP4 = log2K / 2;
     static constexpr bool HAS2 = (log2K & 1) != 0;
     static constexpr int WG = rowgeom::wg(K);              // threads per workgroup (blocks of K <= 64 lanes are packed)
@@ -91,18 +94,28 @@ template <int K> struct RowShape {
 #else
     static constexpr bool RADIX8X16 = false;
 #endif
-    static constexpr bool WIDE = RADIX16 || RADIX8X16;     // FftTwiddles holds the 15 (7) twiddles of the first wide pass
+    static constexpr bool WIDE = RADIX16 || RADIX8X16 || MIXED;   // FftTwiddles holds the R0 - 1 twiddles of the first wide pass
+    static constexpr int WIDE_R0 = RADIX16 ? 16 : RADIX8X16 ? 8 : MIXED ? R0 : 1;
+    static constexpr int WIDE_R1 = (RADIX16 || RADIX8X16) ? 16 : MIXED ? R1 : 1;
 };
+
+// x mod K for 0 <= x (row and twiddle indices): a mask where K is a power of two, a constant division otherwise
+template <int K>
+__device__ __forceinline__ int wrap_k(int x)
+{
+    if constexpr (rowgeom::pow2(K)) return x & (K - 1); else return x % K;
+}
 
 constexpr int pow4(int s) { return 1 << (2 * s); }
 
-// Ordering point for the block's LDS tile.  A block of K <= 64 lanes lives inside ONE wavefront, whose LDS instructions
-// execute in program order: only the compiler has to be kept from reordering them (the other waves of the workgroup work
-// on other blocks and are never waited for).  Larger blocks span several waves and need the workgroup barrier.
+// Ordering point for the block's LDS tile.  A block of K <= 64 lanes, K a power of two, lives inside ONE wavefront, whose LDS
+// instructions execute in program order: only the compiler has to be kept from reordering them (the other waves of the workgroup
+// work on other blocks and are never waited for).  Larger blocks span several waves and need the workgroup barrier, and so do
+// blocks whose K does not divide 64 (they are packed back to back and straddle wavefronts).
 template <int K>
 __device__ __forceinline__ void block_sync()
 {
-    if constexpr (K <= 64) {
+    if constexpr (rowgeom::wave_local(K)) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     } else {
@@ -144,7 +157,7 @@ template <int K> struct FftLayout {
             // radix-16 passes: 16 neighbouring lanes touch rows tq + 16 r (reads, phase A), 16 tq + u (pass-0 writes); rotating the
             // low four row bits by the next four keeps the slots of both patterns distinct mod 32 (b64 slots, odd row stride)
             return (row & ~15) | ((row + (row >> 4)) & 15);
-        } else if constexpr (K >= 64) {
+        } else if constexpr (K >= 64 && !RowShape<K>::MIXED) {
             const int b = (row >> 4) & 3, c = (row >> 2) & 3, d = row & 3;
             return (row & ~63) | (16 * b + 4 * ((c + b) & 3) + ((d + b) & 3));
         } else {
@@ -162,21 +175,16 @@ template <int K> struct FftLayout {
 // and writes, because loads cannot be hoisted across the ordering points.
 template <int K> struct FftTwiddles {
     cf w[RowShape<K>::WIDE ? 1 : RowShape<K>::NP4][3];
-    cf w16[RowShape<K>::RADIX16 ? 15 : RowShape<K>::RADIX8X16 ? 7 : 1];   // wide first pass: W_K^{tq u}, u = 1 .. 15 (radix 16) / 1 .. 7 (radix 8)
+    cf w16[RowShape<K>::WIDE_R0 > 1 ? RowShape<K>::WIDE_R0 - 1 : 1];       // wide first pass of radix R0: W_K^{tq u}, u = 1 .. R0 - 1
 };
 
 template <int K>
 __device__ __forceinline__ void load_fft_twiddles(FftTwiddles<K>& t, int lane, const cf* __restrict__ wK)
 {
     using S = RowShape<K>;
-    if constexpr (S::RADIX16) {
-        const int tq16 = lane % (K / 16);
-        static_for<1, 16>([&](auto ui) { constexpr int u = decltype(ui)::value; t.w16[u - 1] = wK[(tq16 * u) & (K - 1)]; });
-        return;
-    }
-    if constexpr (S::RADIX8X16) {
-        const int tq8 = lane % (K / 8);
-        static_for<1, 8>([&](auto ui) { constexpr int u = decltype(ui)::value; t.w16[u - 1] = wK[(tq8 * u) & (K - 1)]; });
+    if constexpr (S::WIDE) {
+        const int tq0 = lane % (K / S::WIDE_R0);
+        static_for<1, S::WIDE_R0>([&](auto ui) { constexpr int u = decltype(ui)::value; t.w16[u - 1] = wK[wrap_k<K>(tq0 * u)]; });
         return;
     }
     const int tq = lane % S::RG;
@@ -192,89 +200,53 @@ __device__ __forceinline__ void load_fft_twiddles(FftTwiddles<K>& t, int lane, c
     });
 }
 
-// K = 256: two radix-16 Stockham passes, in place.  Lane (tq, cg), tq = lane % 16, owns rows tq + 16 r (r = 0 .. 15) of column
-// group cg (ceil(M / 16) columns): pass 0 writes rows 16 tq + u with twiddle W_K^{tq u}, pass 1 reads and writes the lane's own
-// rows tq + 16 u and leaves natural order.  The 16-point butterflies are the compile-time codelet Dft<16>.
-template <int K, int M, bool INV>
-__device__ __forceinline__ void lds_subcarrier_fft16(cf* tile, int lane, const FftTwiddles<K>& twd)
+// Two Stockham passes of radix R0 and R1 (R0 R1 = K), in place.  Pass 0: lane (tq, cg), tq = lane % (K / R0), owns rows
+// tq + (K / R0) r (r < R0) of column group cg (ceil(M / R0) columns) and writes rows R0 tq + u with twiddle W_K^{tq u}.  Pass 1:
+// tq = lane % R0 reads and writes the lane's own rows tq + R0 u (u < R1) and leaves natural order.  The butterflies are the
+// compile-time codelets Dft<R0>, Dft<R1>.  K = 256 = 16 x 16 and K = 128 = 8 x 16 replace four radix-4 passes; subcarrier counts
+// that are not a power of two (K = 96 = 6 x 16, 12 = 1 x 12, 80 = 5 x 16 ...) have no other form.  R0 = 1: one pass.
+template <int K, int M, bool INV, int R0, int R1>
+__device__ __forceinline__ void lds_subcarrier_fft2(cf* tile, int lane, const FftTwiddles<K>& twd)
 {
-    static_assert(K == 256, "two radix-16 passes");
+    static_assert(R0 * R1 == K, "two-pass plan");
     using LY = FftLayout<K>;
-    constexpr int RG = K / 16, CMAX = (M + 15) / 16;
-    const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
-    static_for<0, 2>([&](auto si) {
-        constexpr int s = decltype(si)::value;
-        cf x[CMAX][16];
+    if constexpr (R0 > 1) {
+        constexpr int RG = K / R0, CMAX = (M + R0 - 1) / R0;
+        const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+        cf x[CMAX][R0];
         static_for<0, CMAX>([&](auto ci) {
             constexpr int c = decltype(ci)::value;
-            if (c0 + c < M) static_for<0, 16>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
+            if (c0 + c < M) static_for<0, R0>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
         });
         block_sync<K>();                                          // everyone has its inputs in registers
         static_for<0, CMAX>([&](auto ci) {
             constexpr int c = decltype(ci)::value;
             if (c0 + c < M) {
-                Dft<16, INV>::run(x[c]);
-                static_for<0, 16>([&](auto ui) {
-                    constexpr int u = decltype(ui)::value;
-                    if constexpr (s == 0) {
-                        cf y = x[c][u];
-                        if constexpr (u > 0) y = cmul_dir<INV>(y, twd.w16[u - 1]);
-                        tile[LY::slot(16 * tq + u) * M + c0 + c] = y;
-                    } else {
-                        tile[(tq + RG * u) * M + c0 + c] = x[c][u];      // natural order
-                    }
-                });
-            }
-        });
-        block_sync<K>();
-    });
-}
-
-// K = 128: a radix-8 pass (lane (tq, cg), tq = lane % 16: rows tq + 16 r, r < 8, of column group cg = lane / 16 -> rows 8 tq + u with
-// twiddle W_K^{tq u}) and a radix-16 pass (tq = lane % 8: rows tq + 8 r, r < 16, of column group lane / 8, read and written by the same
-// lane, natural order out).  Codelets Dft<8> and Dft<16>.
-template <int K, int M, bool INV>
-__device__ __forceinline__ void lds_subcarrier_fft8x16(cf* tile, int lane, const FftTwiddles<K>& twd)
-{
-    static_assert(K == 128, "radix 8 x radix 16");
-    using LY = FftLayout<K>;
-    {
-        constexpr int RG = K / 8, CMAX = (M + 7) / 8;
-        const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
-        cf x[CMAX][8];
-        static_for<0, CMAX>([&](auto ci) {
-            constexpr int c = decltype(ci)::value;
-            if (c0 + c < M) static_for<0, 8>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
-        });
-        block_sync<K>();
-        static_for<0, CMAX>([&](auto ci) {
-            constexpr int c = decltype(ci)::value;
-            if (c0 + c < M) {
-                Dft<8, INV>::run(x[c]);
-                static_for<0, 8>([&](auto ui) {
+                Dft<R0, INV>::run(x[c]);
+                static_for<0, R0>([&](auto ui) {
                     constexpr int u = decltype(ui)::value;
                     cf y = x[c][u];
                     if constexpr (u > 0) y = cmul_dir<INV>(y, twd.w16[u - 1]);
-                    tile[LY::slot(8 * tq + u) * M + c0 + c] = y;
+                    tile[LY::slot(R0 * tq + u) * M + c0 + c] = y;
                 });
             }
         });
         block_sync<K>();
     }
     {
-        constexpr int RG = K / 16, CMAX = (M + 15) / 16;
+        constexpr int RG = K / R1, CMAX = (M + R1 - 1) / R1;
         const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
-        cf x[CMAX][16];
+        cf x[CMAX][R1];
         static_for<0, CMAX>([&](auto ci) {
             constexpr int c = decltype(ci)::value;
-            if (c0 + c < M) static_for<0, 16>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
+            if (c0 + c < M) static_for<0, R1>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
         });
         block_sync<K>();
         static_for<0, CMAX>([&](auto ci) {
             constexpr int c = decltype(ci)::value;
             if (c0 + c < M) {
-                Dft<16, INV>::run(x[c]);
-                static_for<0, 16>([&](auto ui) { constexpr int u = decltype(ui)::value; tile[(tq + RG * u) * M + c0 + c] = x[c][u]; });
+                Dft<R1, INV>::run(x[c]);
+                static_for<0, R1>([&](auto ui) { constexpr int u = decltype(ui)::value; tile[(tq + RG * u) * M + c0 + c] = x[c][u]; });      // natural order
             }
         });
         block_sync<K>();
@@ -286,12 +258,8 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
 {
     using S = RowShape<K>;
     using LY = FftLayout<K>;
-    if constexpr (S::RADIX16) {
-        lds_subcarrier_fft16<K, M, INV>(tile, lane, twd);
-        return;
-    }
-    if constexpr (S::RADIX8X16) {
-        lds_subcarrier_fft8x16<K, M, INV>(tile, lane, twd);
+    if constexpr (S::WIDE) {
+        lds_subcarrier_fft2<K, M, INV, S::WIDE_R0, S::WIDE_R1>(tile, lane, twd);
         return;
     }
 #ifndef GFDM_NO_R16_TAIL
@@ -322,7 +290,7 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
     const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
     const cf* rb[4];
     static_for<0, 4>([&](auto ri) { constexpr int r = decltype(ri)::value; rb[r] = tile + LY::slot(tq + RG * r) * M + c0; });
-    static_for<FIRST, S::NP4>([&](auto si) {
+    static_for<FIRST, S::WIDE ? 0 : S::NP4>([&](auto si) {
         constexpr int s = decltype(si)::value;
         constexpr int str = pow4(s), len = K / str, ms = len / 4;
         constexpr bool last = (s == S::NP4 - 1) && !S::HAS2;      // the pass that leaves the data in natural order
@@ -616,7 +584,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     } else {
         static_for<0, L>([&](auto ii) {
             constexpr int i = decltype(ii)::value;
-            const cf* rb = X + ((q + i - L / 2 + K) & (K - 1)) * MS;
+            const cf* rb = X + wrap_k<K>(q + i - L / 2 + K) * MS;
             static_for<0, M>([&](auto mi) {
                 constexpr int m = decltype(mi)::value;
                 s[m] = cfma(tap(std::integral_constant<int, ((i + L / 2) % L) * M + m>{}), rb[m], s[m]);
@@ -661,12 +629,22 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                 });
             }
             if (pc) {                                                                                    // adv:59-71, 78-91
-                for (int off = 1; off < 64 && off < K; off <<= 1) acc += __shfl_xor(acc, off, 64);
-                if constexpr (K > 64) {
-                    if ((q & 63) == 0) red[q >> 6] = acc;
+                if constexpr (S::MIXED) {
+                    // the block's lanes are not aligned to wavefronts: sum through the (free) tile
+                    float* part = reinterpret_cast<float*>(X);
+                    part[q] = acc;
                     block_sync<K>();
                     acc = 0.f;
-                    static_for<0, K / 64>([&](auto wi) { acc += red[decltype(wi)::value]; });
+                    for (int i = 0; i < K; ++i) acc += part[i];
+                    block_sync<K>();
+                } else {
+                    for (int off = 1; off < 64 && off < K; off <<= 1) acc += __shfl_xor(acc, off, 64);
+                    if constexpr (K > 64) {
+                        if ((q & 63) == 0) red[q >> 6] = acc;
+                        block_sync<K>();
+                        acc = 0.f;
+                        static_for<0, K / 64>([&](auto wi) { acc += red[decltype(wi)::value]; });
+                    }
                 }
                 const float phi = acc / (float)(ic.n_active * M);
                 float sn, cs;
@@ -686,8 +664,8 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
             } else {
                 static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = dec[m]; });
                 block_sync<K>();
-                const cf* below = X + ((q - 1 + K) & (K - 1)) * M;
-                const cf* above = X + ((q + 1) & (K - 1)) * M;
+                const cf* below = X + wrap_k<K>(q - 1 + K) * M;
+                const cf* above = X + wrap_k<K>(q + 1) * M;
                 static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; nb[m] = below[m] + above[m]; });
             }
             if constexpr (ICSYM) {
@@ -812,7 +790,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
         static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = mk(0.f, 0.f); });
         static_for<0, L>([&](auto ii) {
             constexpr int i = decltype(ii)::value;
-            const cf* rb = X + ((q - i + L / 2 + K) & (K - 1)) * M;
+            const cf* rb = X + wrap_k<K>(q - i + L / 2 + K) * M;
             static_for<0, PART>([&](auto mi) {
                 constexpr int m = decltype(mi)::value;
                 v[m] = cfma(rb[m], tap(std::integral_constant<int, ((i + L / 2) % L) * M + m>{}), v[m]);

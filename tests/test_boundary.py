@@ -134,5 +134,8 @@ def test_row_lane_kernels_build_through_hiprtc(tmp_path, monkeypatch):
         assert L.gfdm_hip_jit_build_for_testing(7, 16, 2, part) == 0
     assert time.perf_counter() - t0 < 0.5 * first + 0.2            # served from the cache
     assert L.gfdm_hip_jit_build_for_testing(13, 32, 4, 1) == 0, L.gfdm_hip_last_error()      # overlap 4, IC kernels
-    for (M, K, Lp) in ((9, 96, 2), (127, 16, 2), (9, 1024, 2), (2, 16, 2), (9, 64, 1), (33, 64, 2)):     # K not a power of two, M / K / L out of range
+    assert L.gfdm_hip_jit_build_for_testing(5, 12, 2, 0) == 0, L.gfdm_hip_last_error()       # K = 12: not a power of two, one radix-12 pass
+    assert L.gfdm_hip_jit_build_for_testing(3, 48, 4, 1) == 0, L.gfdm_hip_last_error()       # K = 48 = 3 x 16
+    # K with a factor the two-pass plan cannot hold (34 = 2 x 17, 200 = 20 x 10, 320 > 256), M / K / L out of range
+    for (M, K, Lp) in ((9, 34, 2), (9, 200, 2), (9, 320, 2), (127, 16, 2), (9, 1024, 2), (2, 16, 2), (9, 64, 1), (33, 64, 2), (9, 6, 8)):
         assert L.gfdm_hip_jit_build_for_testing(M, K, Lp, 0) != 0

@@ -388,8 +388,10 @@ def test_baseline_shapes_run_on_the_tuned_family():
         assert gfdm_amd.Modulator(M, K, L, taps).kernel_name() == "rowlane"
         assert gfdm_amd.Demodulator(M, K, L, taps).kernel_name() == "rowlane"
         assert gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points()).kernel_name() == "rowlane"
-    taps = get_frequency_domain_filter("rrc", 0.35, 25, 96, 2)
-    assert gfdm_amd.Demodulator(25, 96, 2, taps).kernel_name() == "generic_lds"
+    taps = get_frequency_domain_filter("rrc", 0.35, 127, 16, 2)                  # M > 32: no register codelet
+    assert gfdm_amd.Demodulator(127, 16, 2, taps).kernel_name() == "generic_lds"
+    taps = get_frequency_domain_filter("rrc", 0.35, 9, 34, 2)                    # K = 2 x 17: no two-pass plan
+    assert gfdm_amd.Demodulator(9, 34, 2, taps).kernel_name() == "generic_lds"
 
 
 @pytest.mark.parametrize("M,K,L,alpha", SHAPES[:4])
@@ -520,11 +522,13 @@ def test_generic_family_any_subcarrier_count(M, K, L):
         assert rel_err(adv.demodulate_equalize(xe, feq)[keep], ref[keep]) < TOL
 
 
-@pytest.mark.parametrize("M,K,L,alpha", [(7, 16, 2, 0.3), (13, 32, 4, 0.4), (11, 8, 2, 0.5), (27, 128, 2, 0.2), (6, 256, 2, 0.3), (28, 64, 2, 0.1), (5, 4, 8, 0.5)])
+@pytest.mark.parametrize("M,K,L,alpha", [(7, 16, 2, 0.3), (13, 32, 4, 0.4), (11, 8, 2, 0.5), (27, 128, 2, 0.2), (6, 256, 2, 0.3), (28, 64, 2, 0.1), (5, 4, 8, 0.5),
+                                         (10, 96, 2, 0.35), (21, 12, 2, 0.35), (9, 48, 4, 0.3), (7, 240, 2, 0.2), (15, 80, 2, 0.3), (9, 15, 2, 0.4), (3, 6, 2, 0.5),
+                                         (4, 100, 2, 0.5), (5, 20, 6, 0.4)])
 def test_row_lane_kernels_instantiated_at_run_time(M, K, L, alpha, tmp_path, monkeypatch):
-    """Shapes outside the compiled list with a power-of-two K get the row-lane kernels instantiated through hiprtc when the handle
-    is created (gfdm_jit.hip): every mode against the oracle, the generic family on the same inputs, and the switch that turns the
-    run-time instantiation off."""
+    """Shapes outside the compiled list get the row-lane kernels instantiated through hiprtc when the handle is created
+    (gfdm_jit.hip) -- K a power of two, or K = R0 x R1 with both factors <= 16 (96 = 6 x 16, 12, 48 = 3 x 16, 240 = 15 x 16, 80, 15,
+    6, 100 = 10 x 10, 20): every mode against the oracle, and the switch that turns the run-time instantiation off."""
     import gfdm_amd
     monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(tmp_path))       # cold cache: really compile
     rng = np.random.default_rng(31 * M + K + L)

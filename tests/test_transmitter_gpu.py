@@ -79,7 +79,7 @@ def test_transmitter_device_path_and_oracles_at_batch():
 def test_transmitter_generic_family_and_validation():
     import gfdm_amd
     rng = np.random.default_rng(5)
-    M, K, A, L = 7, 12, 8, 2                                   # not an instantiated shape: generic LDS family
+    M, K, A, L = 7, 12, 8, 2                                   # not a compiled shape, K not a power of two
     taps = get_frequency_domain_filter("rrc", 0.3, M, K, L)
     smap = np.array([1, 2, 3, 4, 7, 8, 10, 11])
     cp, cs, ramp = 5, 3, 2
@@ -87,16 +87,19 @@ def test_transmitter_generic_family_and_validation():
     pre = [rng.standard_normal(11) + 1j * rng.standard_normal(11) for _ in range(2)]
     nt = R.normalize_taps(taps, M)
     for per_ts in (True, False):
-        tx = gfdm_amd.Transmitter(M, K, A, cp, cs, ramp, smap[::-1], per_ts, L, taps, window, [0, 2], pre)   # unsorted map: the reference sorts it
-        assert tx.kernel_name() == "generic_lds"
+        with gfdm_amd.generic_family_for_testing():
+            tx = gfdm_amd.Transmitter(M, K, A, cp, cs, ramp, smap[::-1], per_ts, L, taps, window, [0, 2], pre)   # unsorted map: the reference sorts it
+        txj = gfdm_amd.Transmitter(M, K, A, cp, cs, ramp, smap[::-1], per_ts, L, taps, window, [0, 2], pre)     # K = 12: one radix-12 pass, run-time instantiated
+        assert (tx.kernel_name(), txj.kernel_name()) == ("generic_lds", "rowlane_jit")
         sym = qpsk(rng, (4, A * M - 3))                        # fewer symbols than slots: the rest is zero
         for port, s in enumerate((0, 2)):
             ref = R.transmit(sym, nt, M, K, L, smap, per_ts, cp, cs, ramp, window, s, pre[port])
             assert rel_err(tx.transmit(sym, ninput_size=A * M - 3)[port], ref) < TOL
+            assert rel_err(txj.transmit(sym, ninput_size=A * M - 3)[port], ref) < TOL
         # only the 2*ramp_len window taps given (lib/add_cyclic_prefix_cc.cc:42-56)
         short_window = np.concatenate((window[:ramp], window[-ramp:]))
         tx2 = gfdm_amd.Transmitter(M, K, A, cp, cs, ramp, smap, per_ts, L, taps, short_window, [0, 2], pre)
-        assert np.array_equal(tx2.transmit(sym, ninput_size=A * M - 3)[1], tx.transmit(sym, ninput_size=A * M - 3)[1])
+        assert np.array_equal(tx2.transmit(sym, ninput_size=A * M - 3)[1], txj.transmit(sym, ninput_size=A * M - 3)[1])
     with pytest.raises(ValueError, match="MUST be unique"):
         gfdm_amd.Transmitter(M, K, A, cp, cs, ramp, [1, 1, 3, 4, 7, 8, 10, 11], True, L, taps, window, [0], pre[:1])
     with pytest.raises(ValueError, match="number of window taps"):
