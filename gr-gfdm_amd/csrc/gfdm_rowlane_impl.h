@@ -10,7 +10,8 @@
 //            (gfdm_dft.h), twiddle W_N^{q m} from a [M][K] table (coalesced), row -> the block's single LDS tile
 //   phase B  K-point FFT over q for all M columns: Stockham passes IN PLACE in the tile, as few and as wide as the lane count
 //            allows -- K = 64: radix 4 straight from the registers (lane-row transposes) + ONE radix-16 pass; K = 128: radix 8 +
-//            radix 16; K = 256: radix 16 + radix 16; otherwise radix-4 passes (+ one radix-2).  Lane (tq, cg) owns the rows
+//            radix 16; K = 256: radix 16 + radix 16; K not a power of two: radix R0 + radix R1, K = R0 R1, both <= 16 (96 = 6 x 16,
+//            12 = one radix-12 pass); otherwise radix-4 passes (+ one radix-2).  Lane (tq, cg) owns the rows
 //            tq + (K / R) r of column group cg: every pass reads exactly those rows, so addresses are base + immediates.  During
 //            the passes the rows sit at a slot permutation (FftLayout) chosen so that no pass access has an LDS bank conflict;
 //            the last pass writes natural order.
@@ -19,8 +20,9 @@
 //   IC       d_new = d0 - g (*) (dec_{k-1} + dec_{k+1}) with the M-tap circular kernel g = IDFT_M(ic)/M; for K = 64 the
 //            neighbour rows come by DPP wave rotate (no LDS, no ordering point), otherwise through the tile
 //   output   row -> tile, linear read, coalesced store
-// Blocks of K <= 64 lanes live inside one wavefront: their LDS accesses are ordered by the wave's program order, so they
-// are packed four waves to a workgroup and never wait on s_barrier (block_sync).
+// Blocks of K <= 64 lanes, K a power of two, live inside one wavefront: their LDS accesses are ordered by the wave's program
+// order, so they are packed four waves to a workgroup and never wait on s_barrier (block_sync).  Other K below 128 are packed back
+// to back (floor(256 / K) blocks per workgroup) and ordered by the workgroup barrier.
 // HBM traffic: x (+ f_eq) in, out out (streamed: non-temporal loads and stores, gfdm_dft.h); nothing else leaves the CU.
 // The modulator is the transposed flow; with TXMODE the resource mapper becomes its load stage and cyclic prefix / ramp / preamble
 // its store stage (gfdm_tx.h).
