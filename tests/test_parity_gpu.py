@@ -566,3 +566,50 @@ def test_row_lane_kernels_instantiated_at_run_time(M, K, L, alpha, tmp_path, mon
     frames = rng.standard_normal((B, N + 12)) + 1j * rng.standard_normal((B, N + 12))
     frames[:, 5:5 + N] = xe
     assert rel_err(dem.demodulate_frames(frames, feq), R.demap_from_resources(R.demodulate(xe, nt, M, K, L, feq), M, K, smap, True)) < TOL
+
+
+def test_handles_on_concurrent_host_threads():
+    """GNU Radio runs every block's work() on its own thread: a modulator, two receivers and an estimator, each with its OWN handle,
+    working at the same time from different host threads (host-pointer entry points, ctypes drops the GIL) must give exactly the
+    results of the same calls made one after the other.  Handles are not shared between threads (boundary contract)."""
+    import threading
+    import gfdm_amd
+    rng = np.random.default_rng(77)
+    M, K, L = 9, 64, 2
+    N = M * K
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    pre = (rng.standard_normal(2 * K) + 1j * rng.standard_normal(2 * K)) / np.sqrt(2)
+    sym = qpsk(rng, (40, N)).astype(np.complex64)
+    feq = (np.fft.fft(np.array([1, .5, .1j]), N)[None, :] * np.ones((40, 1))).astype(np.complex64)
+    rxp = (rng.standard_normal((40, 2 * K)) + 1j * rng.standard_normal((40, 2 * K))).astype(np.complex64)
+
+    def jobs():
+        mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+        adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+        est = gfdm_amd.ChannelEstimator(M, K, 52, True, 1, pre)
+        small = gfdm_amd.Demodulator(5, 12, 2, get_frequency_domain_filter("rrc", 0.3, 5, 12, 2))     # a run-time instantiated shape
+        x = mod.modulate(sym)
+        return [lambda: mod.modulate(sym), lambda: dem.demodulate(x), lambda: adv.demodulate_equalize(x, feq),
+                lambda: est.estimate_frame(rxp), lambda: small.demodulate(sym[:, :60])]
+
+    serial = [f() for f in jobs()]
+    fns = jobs()
+    results, errors = [None] * len(fns), []
+
+    def worker(i):
+        try:
+            out = None
+            for _ in range(25):                       # single blocks and whole batches interleave on the GPU
+                out = fns[i]()
+            results[i] = out
+        except Exception as e:                        # noqa: BLE001 - reported below
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(fns))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for a, b in zip(serial, results):
+        assert np.array_equal(a, b)
