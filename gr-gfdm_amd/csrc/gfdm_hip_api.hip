@@ -107,7 +107,7 @@ void unit_roots(std::vector<cf>& dst, int n)
 }
 
 // Build the plan: normalise taps exactly as the reference constructors do, derive IC taps and twiddle tables.
-int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int device, bool receiver)
+int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int device, bool receiver, unsigned jit_parts = 0)
 {
     if (M < 1 || K < 1 || L < 1 || taps == nullptr) return fail(GFDM_HIP_EINVAL, "timeslots, subcarriers, overlap must be >= 1 and taps non-NULL");
     if (ntaps != M * L) {
@@ -206,9 +206,12 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
             // not in the compiled list: instantiate the row-lane kernels for this shape now (seconds, once per shape and machine --
             // the code object is cached on disk).  Any failure (no hiprtc, no cache directory AND no compiler, ...) leaves the handle
             // on the generic HIP family; the reason stays readable from gfdm_hip_last_error().
+            // Only the parts this kind of handle launches are prepared here (a modulator never compiles receiver kernels); anything
+            // else (the preamble-equalised receivers once an estimator is attached) loads when it is first needed.
             std::string why;
             DeviceGuard guard(device);
-            if (gfdm::jit_prepare(M, K, L, why)) pl.family = gfdm::FAMILY_ROWLANE_JIT;
+            if (jit_parts == 0) jit_parts = receiver ? (1u << gfdm::JIT_PART_RX) : (1u << gfdm::JIT_PART_MOD);
+            if (gfdm::jit_prepare(M, K, L, jit_parts, why)) pl.family = gfdm::FAMILY_ROWLANE_JIT;
             else g_last_error = "run-time instantiation of the row-lane kernels failed, using the generic family: " + why;
         }
     }
@@ -614,7 +617,7 @@ int gfdm_hip_advanced_receiver_create(gfdm_hip_advanced_receiver** out, int time
         if (subcarrier_map[i] < 0 || subcarrier_map[i] >= subcarriers) return fail(GFDM_HIP_EINVAL, "subcarrier_map entry out of range");
     gfdm_hip_advanced_receiver* a = new (std::nothrow) gfdm_hip_advanced_receiver();
     if (!a) return fail(GFDM_HIP_ENOMEM, "out of host memory");
-    int rc = plan_create(a->plan, timeslots, subcarriers, overlap, taps, ntaps, device, true);
+    int rc = plan_create(a->plan, timeslots, subcarriers, overlap, taps, ntaps, device, true, (1u << gfdm::JIT_PART_RX) | (1u << gfdm::JIT_PART_RX_IC));
     if (rc != GFDM_HIP_OK) { delete a; return rc; }
 
     const cf* pts = reinterpret_cast<const cf*>(constellation_points);
@@ -1250,6 +1253,13 @@ int est_attach(const Plan& pl, const gfdm_hip_channel_estimator*& slot, const gf
         return fail(GFDM_HIP_EINVAL, buf);
     }
     if (c && c->plan.device != pl.device) return fail(GFDM_HIP_EINVAL, "estimator and receiver live on different devices");
+    if (c && pl.family == gfdm::FAMILY_ROWLANE_JIT) {
+        // the preamble-equalised receive kernels of a run-time instantiated shape: compile / load them now rather than in the first call
+        std::string why;
+        DeviceGuard guard(pl.device);
+        if (!gfdm::jit_prepare(pl.dp.M, pl.dp.K, pl.dp.L, 1u << gfdm::JIT_PART_RX_PREAMBLE, why))
+            return fail(GFDM_HIP_EHIP, "run-time instantiation of the preamble-equalised receive kernels failed: " + why);
+    }
     slot = c;
     return GFDM_HIP_OK;
 }

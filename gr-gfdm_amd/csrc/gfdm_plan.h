@@ -92,7 +92,9 @@ hipError_t jit_launch_estimate(const EstPlan& e, cf* out, const cf* in, int64_t 
 #include <string>
 namespace gfdm {
 bool jit_eligible(int M, int K, int L);
-bool jit_prepare(int M, int K, int L, std::string& err);
+// parts of a shape (one hiprtc program each): a handle prepares the ones its kind launches, the others load at first use
+enum { JIT_PART_RX = 0, JIT_PART_RX_IC = 1, JIT_PART_RX_PREAMBLE = 2, JIT_PART_MOD = 3, JIT_PART_EST = 4, JIT_NUM_PARTS = 5 };
+bool jit_prepare(int M, int K, int L, unsigned parts, std::string& err);      // parts: bit p = part p
 bool jit_prepare_estimate(int M, int K, std::string& err);
 bool jit_build_only(int M, int K, int L, int part, std::string& err);
 

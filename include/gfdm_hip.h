@@ -68,12 +68,14 @@ int gfdm_hip_force_generic_family_for_testing(int enable);
 /* Run-time instantiation of the tuned (row-lane) kernels for shapes outside the library's compiled list: a handle for a shape with
  * a power-of-two number of subcarriers (4 .. 512) or one that is a product of two factors <= 16 (12, 20, 48, 96, 100, 240 ...; at most 256),
  * 3 .. 32 timeslots and overlap 2 .. 8 (every such shape fits: the largest tile, 512 x 32, is 131 KB of the CU's 160 KB LDS) gets the kernels compiled for exactly that
- * shape through hiprtc when it is created (1-10 s per part, four parts; the code objects are cached under $GFDM_HIP_CACHE_DIR,
+ * shape through hiprtc when it is created (1-10 s per part; a handle compiles only the parts of its kind -- a modulator the
+ * modulator kernels, a receiver the receive kernels, ... -- the rest at first use; the code objects are cached under $GFDM_HIP_CACHE_DIR,
  * else $XDG_CACHE_HOME/gfdm_hip, else ~/.cache/gfdm_hip, so this happens once per shape and machine) and reports kernel_name
  * "rowlane_jit".  Enabled by default; gfdm_hip_set_jit(0) makes such handles use the generic kernel family instead (no compile
  * step, several times slower kernels).  Returns the previous setting.  If hiprtc is unavailable the generic family is used. */
 int gfdm_hip_set_jit(int enable);
-/* TEST HOOK: compile (or find in the disk cache) part 0..3 of the row-lane kernels for a shape through hiprtc WITHOUT loading it --
+/* TEST HOOK: compile (or find in the disk cache) part 0..4 (receive, receive + IC, preamble-equalised receive, modulate, estimator) of
+ * the row-lane kernels for a shape through hiprtc WITHOUT loading it --
  * needs no GPU, so the CPU-side tests can check that the embedded kernel sources build. */
 int gfdm_hip_jit_build_for_testing(int timeslots, int subcarriers, int overlap, int part);
 const char* gfdm_hip_version(void);

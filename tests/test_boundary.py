@@ -124,18 +124,19 @@ def test_row_lane_kernels_build_through_hiprtc(tmp_path, monkeypatch):
     monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(tmp_path))
     L = gfdm_amd.lib()
     t0 = time.perf_counter()
-    for part in range(4):
+    for part in range(5):
         assert L.gfdm_hip_jit_build_for_testing(7, 16, 2, part) == 0, L.gfdm_hip_last_error()
     first = time.perf_counter() - t0
     files = sorted(p.name for p in tmp_path.iterdir())
-    assert len([f for f in files if f.endswith(".hsaco")]) == 4 and len([f for f in files if f.endswith(".names")]) == 4
+    assert len([f for f in files if f.endswith(".hsaco")]) == 5 and len([f for f in files if f.endswith(".names")]) == 5
     t0 = time.perf_counter()
-    for part in range(4):
+    for part in range(5):
         assert L.gfdm_hip_jit_build_for_testing(7, 16, 2, part) == 0
     assert time.perf_counter() - t0 < 0.5 * first + 0.2            # served from the cache
     assert L.gfdm_hip_jit_build_for_testing(13, 32, 4, 1) == 0, L.gfdm_hip_last_error()      # overlap 4, IC kernels
     assert L.gfdm_hip_jit_build_for_testing(5, 12, 2, 0) == 0, L.gfdm_hip_last_error()       # K = 12: not a power of two, one radix-12 pass
     assert L.gfdm_hip_jit_build_for_testing(3, 48, 4, 1) == 0, L.gfdm_hip_last_error()       # K = 48 = 3 x 16
     # K with a factor the two-pass plan cannot hold (34 = 2 x 17, 200 = 20 x 10, 320 > 256), M / K / L out of range
+    assert L.gfdm_hip_jit_build_for_testing(7, 16, 2, 5) != 0                                # there is no part 5
     for (M, K, Lp) in ((9, 34, 2), (9, 200, 2), (9, 320, 2), (127, 16, 2), (9, 1024, 2), (2, 16, 2), (9, 64, 1), (33, 64, 2), (9, 6, 8)):
         assert L.gfdm_hip_jit_build_for_testing(M, K, Lp, 0) != 0
