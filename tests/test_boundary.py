@@ -140,3 +140,17 @@ def test_row_lane_kernels_build_through_hiprtc(tmp_path, monkeypatch):
     assert L.gfdm_hip_jit_build_for_testing(7, 16, 2, 5) != 0                                # there is no part 5
     for (M, K, Lp) in ((9, 34, 2), (9, 200, 2), (9, 320, 2), (127, 16, 2), (9, 1024, 2), (2, 16, 2), (9, 64, 1), (33, 64, 2), (9, 6, 8)):
         assert L.gfdm_hip_jit_build_for_testing(M, K, Lp, 0) != 0
+
+
+def test_gnuradio_block_wrappers_compile_against_a_mock_of_the_block_api():
+    """gfdm/gr_blocks.h (complete gr::sync_block subclasses over the batched work() bodies) is compiled only where GNU Radio is
+    installed, which is neither here nor on the GPU box.  Syntax-check it against tests/mock_gnuradio: a test double that declares the
+    few names of GNU Radio's public block API the header uses (no reference code is built with it, nothing links against it)."""
+    import subprocess
+    inc = ["-I" + os.path.join(ROOT, "tests", "mock_gnuradio"), "-I" + os.path.join(ROOT, "gr-gfdm_amd", "cpp", "include"),
+           "-I" + os.path.join(ROOT, "include")]
+    src = os.path.join(ROOT, "gr-gfdm_amd", "cpp", "src", "gr_blocks.cc")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only"] + inc + [src])
+    pre = subprocess.run(["g++", "-std=c++17", "-E"] + inc + [src], check=True, capture_output=True, text=True).stdout
+    for cls in ("hip_simple_modulator_cc", "hip_simple_receiver_cc", "hip_advanced_receiver_sb_cc", "hip_transmitter_cc", "hip_channel_estimator_cc"):
+        assert "class " + cls in pre                      # the mock really switched the wrappers on
