@@ -42,6 +42,13 @@ int fail_hip(hipError_t e, const char* what)
         if (_e != hipSuccess) return fail_hip(_e, #expr);        \
     } while (0)
 
+}  // namespace
+
+int gfdm::api_fail(int code, const std::string& msg) { return fail(code, msg); }
+int gfdm::api_fail_hip(hipError_t e, const char* what) { return fail_hip(e, what); }
+
+namespace {
+
 // test hook (gfdm_hip_force_generic_family_for_testing): handles created while it is set use the generic kernel family
 std::atomic<int> g_force_generic{ 0 };
 // gfdm_hip_set_jit: run-time instantiation (hiprtc) of the row-lane kernels for shapes outside the compiled list

@@ -91,6 +91,9 @@ hipError_t jit_launch_estimate(const EstPlan& e, cf* out, const cf* in, int64_t 
 }  // namespace gfdm
 #include <string>
 namespace gfdm {
+// error reporting shared by the translation units of the C-ABI (thread-local message behind gfdm_hip_last_error)
+int api_fail(int code, const std::string& msg);
+int api_fail_hip(hipError_t e, const char* what);
 bool jit_eligible(int M, int K, int L);
 // parts of a shape (one hiprtc program each): a handle prepares the ones its kind launches, the others load at first use
 enum { JIT_PART_RX = 0, JIT_PART_RX_IC = 1, JIT_PART_RX_PREAMBLE = 2, JIT_PART_MOD = 3, JIT_PART_EST = 4, JIT_NUM_PARTS = 5 };

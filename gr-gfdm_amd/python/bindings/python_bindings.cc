@@ -7,9 +7,11 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <gfdm/add_cyclic_prefix_cc.h>
 #include <gfdm/advanced_receiver_kernel_cc.h>
 #include <gfdm/modulator_kernel_cc.h>
 #include <gfdm/receiver_kernel_cc.h>
+#include <gfdm/resource_mapper_kernel_cc.h>
 #include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm/transmitter_kernel.h>
 
@@ -355,5 +357,78 @@ PYBIND11_MODULE(gfdm_python, m)
             py::array_t<float> cnrs(std::vector<py::ssize_t>{ nframes, self.active_subcarriers() });
             self.estimate_snr_batch(static_cast<float*>(snr.request().ptr), static_cast<float*>(cnrs.request().ptr), cptr(in), nframes);
             return py::make_tuple(snr, cnrs);
+        });
+    // python/bindings/resource_mapper_python.cc:30-87 (same class name, constructor arguments, methods, messages -- the reference's
+    // messages say "Modulator.block_size" here too); both methods additionally accept [nblocks][size] batches
+    py::class_<resource_mapper_kernel_cc>(m, "Resource_mapper")
+        .def(py::init<int, int, int, std::vector<int>, bool>())
+        .def("block_size", &resource_mapper_kernel_cc::block_size)
+        .def("frame_size", &resource_mapper_kernel_cc::frame_size)
+        .def("map_to_resources",
+             [](resource_mapper_kernel_cc& self, const carray array) {
+                 py::buffer_info in = array.request();
+                 const py::ssize_t n = static_cast<py::ssize_t>(self.block_size()), f = static_cast<py::ssize_t>(self.frame_size());
+                 if (in.ndim != 1 && in.ndim != 2) throw std::runtime_error("Only ONE-dimensional vectors allowed!");
+                 const py::ssize_t got = in.ndim == 2 ? in.shape[1] : in.size;
+                 if (got != n)
+                     throw std::runtime_error("Input vector size(" + std::to_string(got) + ") MUST be equal to Modulator.block_size(" +
+                                              std::to_string(n) + ")!");
+                 const long nblocks = in.ndim == 2 ? static_cast<long>(in.shape[0]) : 1;
+                 auto result = in.ndim == 2 ? py::array_t<cfloat>(std::vector<py::ssize_t>{ nblocks, f }) : py::array_t<cfloat>(f);
+                 py::buffer_info out = result.request();
+                 self.map_to_resources_batch(ptr(out), cptr(in), self.block_size(), nblocks);
+                 return result;
+             })
+        .def("demap_from_resources", [](resource_mapper_kernel_cc& self, const carray array) {
+            py::buffer_info in = array.request();
+            const py::ssize_t n = static_cast<py::ssize_t>(self.block_size()), f = static_cast<py::ssize_t>(self.frame_size());
+            if (in.ndim != 1 && in.ndim != 2) throw std::runtime_error("Only ONE-dimensional vectors allowed!");
+            const py::ssize_t got = in.ndim == 2 ? in.shape[1] : in.size;
+            if (got != f)
+                throw std::runtime_error("Input vector size(" + std::to_string(got) + ") MUST be equal to Modulator.block_size(" + std::to_string(f) +
+                                         ")!");
+            const long nblocks = in.ndim == 2 ? static_cast<long>(in.shape[0]) : 1;
+            auto result = in.ndim == 2 ? py::array_t<cfloat>(std::vector<py::ssize_t>{ nblocks, n }) : py::array_t<cfloat>(n);
+            py::buffer_info out = result.request();
+            self.demap_from_resources_batch(ptr(out), cptr(in), self.block_size(), nblocks);
+            return result;
+        });
+
+    // python/bindings/cyclic_prefix_python.cc:31-93 (same class name, keyword arguments, methods, messages); both methods additionally
+    // accept [nblocks][size] batches
+    py::class_<add_cyclic_prefix_cc>(m, "Cyclic_prefixer")
+        .def(py::init<int, int, int, int, std::vector<cfloat>, int>(), py::arg("block_len"), py::arg("cp_len"), py::arg("cs_len"),
+             py::arg("ramp_len"), py::arg("window_taps"), py::arg("cyclic_shift") = 0)
+        .def("block_size", &add_cyclic_prefix_cc::block_size)
+        .def("frame_size", &add_cyclic_prefix_cc::frame_size)
+        .def("cyclic_shift", &add_cyclic_prefix_cc::cyclic_shift)
+        .def("add_cyclic_prefix",
+             [](add_cyclic_prefix_cc& self, const carray array) {
+                 py::buffer_info in = array.request();
+                 const py::ssize_t n = self.block_size(), f = self.frame_size();
+                 if (in.ndim != 1 && in.ndim != 2) throw std::runtime_error("Only ONE-dimensional vectors allowed!");
+                 const py::ssize_t got = in.ndim == 2 ? in.shape[1] : in.size;
+                 if (got != n)
+                     throw std::runtime_error("Input vector size(" + std::to_string(got) + ") MUST be equal to Cyclic_prefix.block_size(" +
+                                              std::to_string(n) + ")!");
+                 const long nblocks = in.ndim == 2 ? static_cast<long>(in.shape[0]) : 1;
+                 auto result = in.ndim == 2 ? py::array_t<cfloat>(std::vector<py::ssize_t>{ nblocks, f }) : py::array_t<cfloat>(f);
+                 py::buffer_info out = result.request();
+                 self.add_cyclic_prefix_batch(ptr(out), cptr(in), self.cyclic_shift(), nblocks);
+                 return result;
+             })
+        .def("remove_cyclic_prefix", [](add_cyclic_prefix_cc& self, const carray array) {
+            py::buffer_info in = array.request();
+            const py::ssize_t n = self.block_size(), f = self.frame_size();
+            if (in.ndim != 1 && in.ndim != 2) throw std::runtime_error("Only ONE-dimensional vectors allowed!");
+            const py::ssize_t got = in.ndim == 2 ? in.shape[1] : in.size;
+            if (got != f)                       // the reference prints block_size() in this message (cyclic_prefix_python.cc:80-84)
+                throw std::runtime_error("Input vector size(" + std::to_string(got) + ") MUST be equal to Cyclic_prefix.frame_size(" +
+                                         std::to_string(n) + ")!");
+            const long nblocks = in.ndim == 2 ? static_cast<long>(in.shape[0]) : 1;
+            auto result = in.ndim == 2 ? py::array_t<cfloat>(std::vector<py::ssize_t>{ nblocks, n }) : py::array_t<cfloat>(n);
+            py::buffer_info out = result.request();
+            self.remove_cyclic_prefix_batch(ptr(out), cptr(in), nblocks);
+            return result;
         });
 }

@@ -4,5 +4,5 @@
 (libgfdm_hip.so).  `filters` generates prototype-filter taps.  Nothing here computes on the CPU.
 """
 from . import filters  # noqa: F401
-from .capi import (AdvancedReceiver, ChannelEstimator, Demodulator, GfdmHipError, Modulator, Transmitter, exported_symbols,  # noqa: F401
+from .capi import (AdvancedReceiver, ChannelEstimator, CyclicPrefixer, Demodulator, GfdmHipError, Modulator, ResourceMapper, Transmitter, exported_symbols,  # noqa: F401
                    generic_family_for_testing, lib, set_jit)

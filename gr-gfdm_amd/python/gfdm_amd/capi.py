@@ -106,6 +106,23 @@ def lib():
         "gfdm_hip_transmitter_modulate_device": (i32, [vp, vp, vp, i32, i64, vp]),
         "gfdm_hip_transmitter_add_frame_host": (i32, [vp, vp, vp, i32, i64]),
         "gfdm_hip_transmitter_add_frame_device": (i32, [vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_resource_mapper_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32, i32]),
+        "gfdm_hip_resource_mapper_destroy": (i32, [vp]),
+        "gfdm_hip_resource_mapper_block_size": (i32, [vp]),
+        "gfdm_hip_resource_mapper_frame_size": (i32, [vp]),
+        "gfdm_hip_resource_mapper_map_host": (i32, [vp, vp, vp, i32, i64]),
+        "gfdm_hip_resource_mapper_map_device": (i32, [vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_resource_mapper_demap_host": (i32, [vp, vp, vp, i32, i64]),
+        "gfdm_hip_resource_mapper_demap_device": (i32, [vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_cyclic_prefixer_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, i32, vp, i32, i32, i32]),
+        "gfdm_hip_cyclic_prefixer_destroy": (i32, [vp]),
+        "gfdm_hip_cyclic_prefixer_block_size": (i32, [vp]),
+        "gfdm_hip_cyclic_prefixer_frame_size": (i32, [vp]),
+        "gfdm_hip_cyclic_prefixer_cyclic_shift": (i32, [vp]),
+        "gfdm_hip_cyclic_prefixer_add_host": (i32, [vp, vp, vp, i32, i64]),
+        "gfdm_hip_cyclic_prefixer_add_device": (i32, [vp, vp, vp, i32, i64, vp]),
+        "gfdm_hip_cyclic_prefixer_remove_host": (i32, [vp, vp, vp, i64]),
+        "gfdm_hip_cyclic_prefixer_remove_device": (i32, [vp, vp, vp, i64, vp]),
         "gfdm_hip_channel_estimator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, i32, i32, vp, i32, i32]),
         "gfdm_hip_channel_estimator_destroy": (i32, [vp]),
         "gfdm_hip_channel_estimator_timeslots": (i32, [vp]),
@@ -611,6 +628,118 @@ class Transmitter(_Kernel):
         out = np.empty((nb, F), np.complex64)
         _check(L.gfdm_hip_transmitter_add_frame_host(self._h, out.ctypes.data, x.ctypes.data, int(cyclic_shift), nb))
         return out
+
+
+class ResourceMapper(_Kernel):
+    """gr::gfdm::resource_mapper_kernel_cc (include/gfdm/resource_mapper_kernel_cc.h:38-60; pybind name Resource_mapper): data symbols
+    <-> the [subcarriers][timeslots] grid, stand-alone (Transmitter and the receivers' frame interface have it fused).  One block or a
+    batch ([nblocks][size]); numpy in -> numpy out (host path), torch in -> torch out (device path, current stream unless given)."""
+    _destroy = "gfdm_hip_resource_mapper_destroy"
+
+    def __init__(self, timeslots, subcarriers, active_subcarriers, subcarrier_map, per_timeslot=True, device=0):
+        smap = np.ascontiguousarray(subcarrier_map, dtype=np.int32)
+        h = ctypes.c_void_p()
+        _check(lib().gfdm_hip_resource_mapper_create(ctypes.byref(h), timeslots, subcarriers, active_subcarriers, smap.ctypes.data, smap.size,
+                                                     int(bool(per_timeslot)), device))
+        self._h = h
+        self._dev = int(device)
+
+    def block_size(self):
+        return lib().gfdm_hip_resource_mapper_block_size(self._h)
+
+    def frame_size(self):
+        return lib().gfdm_hip_resource_mapper_frame_size(self._h)
+
+    def _run(self, host, dev, x, n_in, n_out, size_arg, stream, out=None):
+        size = x.numel() if _is_tensor(x) else np.asarray(x).size
+        if n_in <= 0 or size % n_in:
+            raise RuntimeError("input size(%d) MUST be a multiple of %d!" % (size, n_in))
+        nb = size // n_in
+        if _is_tensor(x):
+            import torch
+            if out is None:
+                out = torch.empty(nb, n_out, dtype=torch.complex64, device=x.device)
+            _check(dev(self._h, self._dp(out, nb * n_out, "out"), self._dp(x, size, "in"), size_arg, nb, self._sp(stream)))
+            return out
+        a = _c64(x)
+        out = np.empty((nb, n_out), np.complex64)
+        _check(host(self._h, out.ctypes.data, a.ctypes.data, size_arg, nb))
+        return out[0] if np.asarray(x).ndim == 1 else out
+
+    def map_to_resources(self, symbols, ninput_size=None, stream=None, out=None):
+        """ninput_size symbols per block (default block_size) -> frame_size grid values per block, unfilled slots zero."""
+        n = self.block_size() if ninput_size is None else int(ninput_size)
+        if n == 0:
+            raise RuntimeError("ninput_size 0: give the number of blocks through a [nblocks][0] input of the C-ABI instead")
+        L = lib()
+        return self._run(L.gfdm_hip_resource_mapper_map_host, L.gfdm_hip_resource_mapper_map_device, symbols, n, self.frame_size(), n, stream, out)
+
+    def demap_from_resources(self, grid, noutput_size=None, stream=None, out=None):
+        n = self.block_size() if noutput_size is None else int(noutput_size)
+        L = lib()
+        return self._run(L.gfdm_hip_resource_mapper_demap_host, L.gfdm_hip_resource_mapper_demap_device, grid, self.frame_size(), n, n, stream, out)
+
+
+class CyclicPrefixer(_Kernel):
+    """gr::gfdm::add_cyclic_prefix_cc (include/gfdm/add_cyclic_prefix_cc.h:40-60; pybind name Cyclic_prefixer): cyclic prefix / suffix
+    with cyclic shift + window ramps, and prefix removal, stand-alone.  One block or a batch; numpy -> numpy, torch -> torch."""
+    _destroy = "gfdm_hip_cyclic_prefixer_destroy"
+
+    def __init__(self, block_len, cp_len, cs_len, ramp_len, window_taps, cyclic_shift=0, device=0):
+        w = _c64(np.asarray(window_taps).ravel())
+        h = ctypes.c_void_p()
+        _check(lib().gfdm_hip_cyclic_prefixer_create(ctypes.byref(h), block_len, cp_len, cs_len, ramp_len, w.ctypes.data, w.size, int(cyclic_shift),
+                                                     device))
+        self._h = h
+        self._dev = int(device)
+
+    def block_size(self):
+        return lib().gfdm_hip_cyclic_prefixer_block_size(self._h)
+
+    def frame_size(self):
+        return lib().gfdm_hip_cyclic_prefixer_frame_size(self._h)
+
+    def cyclic_shift(self):
+        return lib().gfdm_hip_cyclic_prefixer_cyclic_shift(self._h)
+
+    def _batch(self, x, n_in):
+        size = x.numel() if _is_tensor(x) else np.asarray(x).size
+        if size % n_in:
+            raise RuntimeError("input size(%d) MUST be a multiple of %d!" % (size, n_in))
+        return size, size // n_in
+
+    def add_cyclic_prefix(self, blocks, cyclic_shift=None, stream=None, out=None):
+        L = lib()
+        s = self.cyclic_shift() if cyclic_shift is None else int(cyclic_shift)
+        N, F = self.block_size(), self.frame_size()
+        size, nb = self._batch(blocks, N)
+        if _is_tensor(blocks):
+            import torch
+            if out is None:
+                out = torch.empty(nb, F, dtype=torch.complex64, device=blocks.device)
+            _check(L.gfdm_hip_cyclic_prefixer_add_device(self._h, self._dp(out, nb * F, "out"), self._dp(blocks, size, "in"), s, nb, self._sp(stream)))
+            return out
+        a = _c64(blocks)
+        out = np.empty((nb, F), np.complex64)
+        _check(L.gfdm_hip_cyclic_prefixer_add_host(self._h, out.ctypes.data, a.ctypes.data, s, nb))
+        return out[0] if np.asarray(blocks).ndim == 1 else out
+
+    generic_work = add_cyclic_prefix
+
+    def remove_cyclic_prefix(self, frames, stream=None, out=None):
+        L = lib()
+        N, F = self.block_size(), self.frame_size()
+        size, nb = self._batch(frames, F)
+        if _is_tensor(frames):
+            import torch
+            if out is None:
+                out = torch.empty(nb, N, dtype=torch.complex64, device=frames.device)
+            _check(L.gfdm_hip_cyclic_prefixer_remove_device(self._h, self._dp(out, nb * N, "out"), self._dp(frames, size, "in"), nb, self._sp(stream)))
+            return out
+        a = _c64(frames)
+        out = np.empty((nb, N), np.complex64)
+        _check(L.gfdm_hip_cyclic_prefixer_remove_host(self._h, out.ctypes.data, a.ctypes.data, nb))
+        return out[0] if np.asarray(frames).ndim == 1 else out
 
 
 class ChannelEstimator(_Kernel):

@@ -270,6 +270,46 @@ int gfdm_hip_advanced_receiver_work_estimated_host(gfdm_hip_advanced_receiver* a
 int gfdm_hip_advanced_receiver_work_estimated_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* rx_preamble,
                                                      int preamble_stride, int noutput_size, int64_t nblocks, void* stream);
 
+/* ---- resource_mapper_kernel_cc (include/gfdm/resource_mapper_kernel_cc.h:38-60, lib/resource_mapper_kernel_cc.cc) -----------------
+ * The stand-alone form of the mapper / demapper that the transmitter and the *_frames_* receivers above have fused into their
+ * kernels: data symbols <-> the [subcarriers][timeslots] grid the modulator reads and the receivers
+ * write.  Blocks back to back: map reads ninput_size symbols per block and writes frame_size; demap reads frame_size and writes
+ * noutput_size.  Errors as the reference constructor / methods throw them (:44-69, :78-82, :95-99), as GFDM_HIP_EINVAL with the
+ * message in gfdm_hip_last_error().  Two deliberate differences: a subcarrier index EQUAL to `subcarriers` is refused (the reference
+ * tests '>' at :65 and then writes past the grid), and the per-subcarrier demapper writes exactly noutput_size symbols (the reference
+ * loop :150-161 writes one more when noutput_size < block_size). */
+typedef struct gfdm_hip_resource_mapper gfdm_hip_resource_mapper;
+int gfdm_hip_resource_mapper_create(gfdm_hip_resource_mapper** out, int timeslots, int subcarriers, int active_subcarriers,
+                                    const int* subcarrier_map, int n_subcarrier_map, int per_timeslot, int device);
+int gfdm_hip_resource_mapper_destroy(gfdm_hip_resource_mapper* m);
+int gfdm_hip_resource_mapper_block_size(const gfdm_hip_resource_mapper* m);      /* timeslots * active_subcarriers   (.h:47) */
+int gfdm_hip_resource_mapper_frame_size(const gfdm_hip_resource_mapper* m);      /* timeslots * subcarriers          (.h:46) */
+/* map_to_resources (.h:50-52, .cc:74-89): grid zeroed, the first ninput_size symbols placed, the rest of the grid stays zero */
+int gfdm_hip_resource_mapper_map_host(gfdm_hip_resource_mapper* m, float* out, const float* in, int ninput_size, int64_t nblocks);
+int gfdm_hip_resource_mapper_map_device(gfdm_hip_resource_mapper* m, void* out, const void* in, int ninput_size, int64_t nblocks, void* stream);
+/* demap_from_resources (.h:53-55, .cc:91-106) */
+int gfdm_hip_resource_mapper_demap_host(gfdm_hip_resource_mapper* m, float* out, const float* in, int noutput_size, int64_t nblocks);
+int gfdm_hip_resource_mapper_demap_device(gfdm_hip_resource_mapper* m, void* out, const void* in, int noutput_size, int64_t nblocks, void* stream);
+
+/* ---- add_cyclic_prefix_cc (include/gfdm/add_cyclic_prefix_cc.h:40-60, lib/add_cyclic_prefix_cc.cc) -------------------------------
+ * Cyclic prefix + suffix with cyclic shift and the block-pinching window ramps, and prefix removal; the stand-alone form of the
+ * transmitter's store stage / the frame receivers' load offset.  window_taps: either the whole window (block_len + cp_len + cs_len
+ * taps) or only its 2 * ramp_len ramp taps (.cc:42-56).  add: block_len samples in, frame_size = block_len + cp_len + cs_len out;
+ * remove: the reverse (frame[cp_len : cp_len + block_len], .cc:100-104).  cyclic_shift must lie in [0, cs_len] with cp_len + shift
+ * <= block_len (the reference reads outside its input otherwise). */
+typedef struct gfdm_hip_cyclic_prefixer gfdm_hip_cyclic_prefixer;
+int gfdm_hip_cyclic_prefixer_create(gfdm_hip_cyclic_prefixer** out, int block_len, int cp_len, int cs_len, int ramp_len, const float* window_taps,
+                                    int n_window_taps, int cyclic_shift, int device);
+int gfdm_hip_cyclic_prefixer_destroy(gfdm_hip_cyclic_prefixer* c);
+int gfdm_hip_cyclic_prefixer_block_size(const gfdm_hip_cyclic_prefixer* c);
+int gfdm_hip_cyclic_prefixer_frame_size(const gfdm_hip_cyclic_prefixer* c);
+int gfdm_hip_cyclic_prefixer_cyclic_shift(const gfdm_hip_cyclic_prefixer* c);
+/* add_cyclic_prefix(out, in, cyclic_shift) (.cc:66-98); generic_work = the constructor's shift */
+int gfdm_hip_cyclic_prefixer_add_host(gfdm_hip_cyclic_prefixer* c, float* out, const float* in, int cyclic_shift, int64_t nblocks);
+int gfdm_hip_cyclic_prefixer_add_device(gfdm_hip_cyclic_prefixer* c, void* out, const void* in, int cyclic_shift, int64_t nblocks, void* stream);
+int gfdm_hip_cyclic_prefixer_remove_host(gfdm_hip_cyclic_prefixer* c, float* out, const float* in, int64_t nblocks);
+int gfdm_hip_cyclic_prefixer_remove_device(gfdm_hip_cyclic_prefixer* c, void* out, const void* in, int64_t nblocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

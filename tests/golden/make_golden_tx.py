@@ -93,3 +93,28 @@ def add_rx_expectations():
 
 if __name__ == "__main__":
     add_rx_expectations()
+
+
+def add_stage_expectations():
+    """The stand-alone stages either side of the modulator / receiver (Resource_mapper, Cyclic_prefixer of the reference's Python
+    bindings), with the reference model:
+      pygfdm_grid      map_to_waveform_resources(symbols, A, K, smap, per_timeslot)       mapping.py:53-55,64-76   [frames][K*M]
+      grid_in          random [frames][K*M] grids (own seed)
+      pygfdm_demapped  demap_from_waveform_resource_grid(grid_in, K, smap)               mapping.py:58-61 (per-timeslot order)
+    The cyclic-prefix stage needs no new arrays: pygfdm_blocks -> pygfdm_frames[port][frame][preamble length:] is
+    pinch_block(add_cyclic_starfix(roll(block, shift), cp, cs), window), stored since round 1."""
+    from pygfdm.mapping import demap_from_waveform_resource_grid
+    for idx, (name, M, K, A, dc_free, L, alpha, cp, cs, ramp, per_ts, shifts, plen, frames, nsym) in enumerate(CASES):
+        path = os.path.join(HERE, name + ".npz")
+        z = dict(np.load(path))
+        rng = np.random.default_rng(0x7F80 + idx)
+        z["pygfdm_grid"] = np.array([map_to_waveform_resources(z["symbols"][f], A, K, z["smap"], per_ts) for f in range(frames)])
+        grid_in = rng.standard_normal((frames, K * M)) + 1j * rng.standard_normal((frames, K * M))
+        z["grid_in"] = grid_in
+        z["pygfdm_demapped"] = np.array([demap_from_waveform_resource_grid(grid_in[f], K, z["smap"]) for f in range(frames)])
+        np.savez_compressed(path, **z)
+        print(name, "grid", z["pygfdm_grid"].shape, "demapped", z["pygfdm_demapped"].shape)
+
+
+if __name__ == "__main__":
+    add_stage_expectations()

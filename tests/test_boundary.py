@@ -62,6 +62,10 @@ def test_pybind_surface_matches_reference():
         assert hasattr(gfdm_python.Demodulator, name)
     for name in ("block_size", "set_ic", "get_ic", "set_phase_compensation", "get_phase_compensation", "demodulate", "demodulate_equalize"):
         assert hasattr(gfdm_python.AdvancedReceiver, name)
+    for name in ("block_size", "frame_size", "map_to_resources", "demap_from_resources"):
+        assert hasattr(gfdm_python.Resource_mapper, name)                  # resource_mapper_python.cc:30-87
+    for name in ("block_size", "frame_size", "cyclic_shift", "add_cyclic_prefix", "remove_cyclic_prefix"):
+        assert hasattr(gfdm_python.Cyclic_prefixer, name)                  # cyclic_prefix_python.cc:31-93
     for name in ("timeslots", "subcarriers", "active_subcarriers", "frame_len", "is_dc_free", "estimate_frame", "estimate_snr"):
         assert hasattr(gfdm_python.Preamble_channel_estimator, name)      # preamble_channel_estimator_python.cc:33-99
     q = gfdm_python.Constellation.qpsk()
@@ -100,7 +104,8 @@ def test_product_sources_do_not_touch_the_oracle():
 
 
 def test_reference_pybind_bindings_compile_unchanged():
-    """Drop-in evidence: gr-gfdm's own kernel bindings (python/bindings/{modulator,demodulator,preamble_channel_estimator}_python.cc) compile,
+    """Drop-in evidence: gr-gfdm's own kernel bindings (python/bindings/{modulator,demodulator,preamble_channel_estimator,resource_mapper,
+    cyclic_prefix}_python.cc -- all five kernel-level classes of its Python module) compile,
     unmodified and from where they lie, against this repository's class headers.  Build-container only: the
     reference checkout does not exist on the GPU box."""
     import subprocess
@@ -111,7 +116,8 @@ def test_reference_pybind_bindings_compile_unchanged():
         pytest.skip("reference checkout not present")
     inc = ["-I" + os.path.join(ROOT, "gr-gfdm_amd", "cpp", "include"), "-I" + os.path.join(ROOT, "include"),
            "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include()]
-    for name in ("modulator_python.cc", "demodulator_python.cc", "preamble_channel_estimator_python.cc"):
+    for name in ("modulator_python.cc", "demodulator_python.cc", "preamble_channel_estimator_python.cc", "resource_mapper_python.cc",
+                 "cyclic_prefix_python.cc"):
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only"] + inc + [os.path.join(ref, name)])
 
 

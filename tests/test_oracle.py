@@ -237,3 +237,32 @@ def test_estimator_snr_properties():
     assert abs(np.mean(snrs) / expect - 1.0) < 0.1
     big, _ = R.estimate_snr(clean, K, A, True)
     assert big > 1e6                                                               # window-free circular preamble: (almost) no odd-bin energy
+
+
+def _pygfdm_grid(g):
+    """pygfdm's mapper builds ceil(n / A) timeslots for n symbols (mapping.py:64-66), the C++ mapper always `timeslots`: pad"""
+    M, K = g["M"], g["K"]
+    grid = g["pygfdm_grid"].reshape(g["pygfdm_grid"].shape[0], K, -1)
+    out = np.zeros((grid.shape[0], K, M), complex)
+    out[:, :, :grid.shape[2]] = grid
+    return out.reshape(-1, K * M)
+
+
+def test_mapper_and_prefixer_oracles_match_pygfdm():
+    """The stand-alone stages (resource_mapper_kernel_cc, add_cyclic_prefix_cc restatements) against the reference's Python model:
+    map_to_waveform_resources, demap_from_waveform_resource_grid (mapping.py:53-76) and roll + add_cyclic_starfix + pinch_block
+    (cyclic_prefix.py, as composed in qa_transmitter_cc.py:50-53)."""
+    from conftest import load_tx_golden, tx_golden_names
+    for name in tx_golden_names():
+        g = load_tx_golden(name)
+        M, K, plen = g["M"], g["K"], g["preambles"].shape[-1]
+        assert np.array_equal(R.map_to_resources(g["symbols"], M, K, g["smap"], g["per_timeslot"]).astype(np.complex64), _pygfdm_grid(g).astype(np.complex64))
+        # pygfdm demaps in per-timeslot order only (mapping.py:58-61)
+        assert np.array_equal(R.demap_from_resources(g["grid_in"], M, K, g["smap"], True), g["pygfdm_demapped"])
+        for port, s in enumerate(g["shifts"]):
+            got = R.add_cyclic_prefix(g["pygfdm_blocks"], g["cp"], g["cs"], g["ramp"], g["window"], int(s))
+            assert rel_err(got, g["pygfdm_frames"][port][:, plen:]) < 1e-12
+            # behind the shifted prefix sits the block itself (where the window ramps have not touched it)
+            back = R.remove_cyclic_prefix(got, g["cp"] + int(s), M * K)
+            clean = slice(max(0, g["ramp"] - g["cp"] - int(s)), M * K - max(0, g["ramp"] - (g["cs"] - int(s))))
+            assert np.array_equal(back[:, clean], g["pygfdm_blocks"][:, clean])
