@@ -7,6 +7,8 @@
  *                                                  pointers advance by block_size), generic_work(out, in) otherwise
  *     lib/transmitter_cc_impl.cc:130-195           per frame: modulate once, add_frame per output port
  *     lib/channel_estimator_cc_impl.cc:88-120      per frame: estimate_frame + estimate_snr, two stream tags
+ *     lib/resource_mapper_cc_impl.cc:86-106, lib/resource_demapper_cc_impl.cc:87-105, lib/cyclic_prefixer_cc_impl.cc:93-110
+ *                                                  per frame: map / demap / add the cyclic prefix
  * With a GPU behind the kernel classes that loop would pay one host-to-device copy, one launch, one device-to-host copy and one
  * synchronisation PER BLOCK (bench.py: single_block_host_us, ~17 us against ~10 us for the CPU kernel).  The functions here take the
  * scheduler's whole `noutput_items` run in one call of the kernels' *_batch methods: same pointers, same return values, same item
@@ -86,6 +88,33 @@ int estimator_work(Kernel& kernel, int noutput_items, const cfloat* in, cfloat* 
     std::vector<float> snr(n_frames), cnrs(static_cast<size_t>(n_frames) * active);
     kernel.estimate_snr_batch(snr.data(), cnrs.data(), in, n_frames);
     for (int i = 0; i < n_frames; ++i) tag(i, snr[i], cnrs.data() + static_cast<size_t>(i) * active, active);
+    return n_frames;
+}
+
+/* resource_mapper_cc_impl::general_work / resource_demapper_cc_impl::general_work (lib/resource_mapper_cc_impl.cc:86-106,
+ * lib/resource_demapper_cc_impl.cc:87-105): n_frames = min(noutput_items / output_vector_size, ninput_items / input_vector_size), whole
+ * vectors only (the blocks never zero-pad), one launch for the run.  The kernel object was constructed as mapper or demapper
+ * (is_mapper), which fixes the direction and the two vector sizes.  Returns the frames produced (consume n_frames * input_vector_size,
+ * return n_frames * output_vector_size). */
+template <class Kernel>
+int mapper_work(Kernel& kernel, bool is_mapper, int noutput_items, int ninput_items, const cfloat* in, cfloat* out)
+{
+    const int in_len = static_cast<int>(kernel.input_vector_size()), out_len = static_cast<int>(kernel.output_vector_size());
+    const int n_frames = std::min(noutput_items / out_len, ninput_items / in_len);
+    if (n_frames <= 0) return 0;
+    if (is_mapper) kernel.map_to_resources_batch(out, in, kernel.block_size(), n_frames);
+    else kernel.demap_from_resources_batch(out, in, kernel.block_size(), n_frames);
+    return n_frames;
+}
+
+/* cyclic_prefixer_cc_impl::general_work (lib/cyclic_prefixer_cc_impl.cc:93-110): n_frames = noutput_items / frame_size, the constructor's
+ * cyclic shift, one launch for the run.  Returns the frames produced (consume n_frames * block_size). */
+template <class Kernel>
+int prefixer_work(Kernel& kernel, int noutput_items, const cfloat* in, cfloat* out)
+{
+    const int n_frames = noutput_items / kernel.frame_size();
+    if (n_frames <= 0) return 0;
+    kernel.add_cyclic_prefix_batch(out, in, kernel.cyclic_shift(), n_frames);
     return n_frames;
 }
 

@@ -7,7 +7,8 @@
  * classes here are the stand-alone form for a flowgraph that links libgfdm_kernels.so directly.
  *
  * Item accounting and tag handling follow the reference: lib/simple_modulator_cc_impl.cc:44-80, lib/simple_receiver_cc_impl.cc:42-77,
- * lib/advanced_receiver_sb_cc_impl.cc:55-123, lib/transmitter_cc_impl.cc:64-195, lib/channel_estimator_cc_impl.cc:44-120.
+ * lib/advanced_receiver_sb_cc_impl.cc:55-123, lib/transmitter_cc_impl.cc:64-195, lib/channel_estimator_cc_impl.cc:44-120,
+ * lib/resource_mapper_cc_impl.cc:43-106, lib/resource_demapper_cc_impl.cc:43-105, lib/cyclic_prefixer_cc_impl.cc:43-110.
  */
 #ifndef INCLUDED_GFDM_GR_BLOCKS_H
 #define INCLUDED_GFDM_GR_BLOCKS_H
@@ -23,11 +24,13 @@
 #include <gnuradio/sync_block.h>
 #include <pmt/pmt.h>
 
+#include <gfdm/add_cyclic_prefix_cc.h>
 #include <gfdm/advanced_receiver_kernel_cc.h>
 #include <gfdm/batched_work.h>
 #include <gfdm/modulator_kernel_cc.h>
 #include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm/receiver_kernel_cc.h>
+#include <gfdm/resource_mapper_kernel_cc.h>
 #include <gfdm/transmitter_kernel.h>
 
 #include <memory>
@@ -225,6 +228,88 @@ private:
         set_output_multiple(fft_len * timeslots);
     }
     std::unique_ptr<preamble_channel_estimator_cc> d_kernel;
+};
+
+/* resource_mapper_cc / resource_demapper_cc (lib/resource_mapper_cc_impl.cc:43-106, lib/resource_demapper_cc_impl.cc:43-105): fixed-rate
+ * general blocks over one resource_mapper_kernel_cc, direction chosen at construction. */
+class hip_resource_mapper_cc : public gr::block
+{
+public:
+    typedef std::shared_ptr<hip_resource_mapper_cc> sptr;
+    static sptr make(int timeslots, int subcarriers, int active_subcarriers, std::vector<int> subcarrier_map, bool per_timeslot = true,
+                     bool is_mapper = true)
+    {
+        return sptr(new hip_resource_mapper_cc(timeslots, subcarriers, active_subcarriers, subcarrier_map, per_timeslot, is_mapper));
+    }
+    void forecast(int noutput_items, gr_vector_int& ninput_items_required) override
+    {
+        ninput_items_required[0] = fixed_rate_noutput_to_ninput(noutput_items);
+    }
+    int fixed_rate_ninput_to_noutput(int ninput) override
+    {
+        return (ninput / static_cast<int>(d_kernel->input_vector_size())) * static_cast<int>(d_kernel->output_vector_size());
+    }
+    int fixed_rate_noutput_to_ninput(int noutput) override
+    {
+        return (noutput / static_cast<int>(d_kernel->output_vector_size())) * static_cast<int>(d_kernel->input_vector_size());
+    }
+    int general_work(int noutput_items, gr_vector_int& ninput_items, gr_vector_const_void_star& input_items,
+                     gr_vector_void_star& output_items) override
+    {
+        const int n_frames = batched::mapper_work(*d_kernel, d_is_mapper, noutput_items, ninput_items[0], static_cast<const gr_complex*>(input_items[0]),
+                                                  static_cast<gr_complex*>(output_items[0]));
+        consume_each(n_frames * static_cast<int>(d_kernel->input_vector_size()));
+        return n_frames * static_cast<int>(d_kernel->output_vector_size());
+    }
+
+private:
+    hip_resource_mapper_cc(int timeslots, int subcarriers, int active_subcarriers, std::vector<int> subcarrier_map, bool per_timeslot, bool is_mapper)
+        : gr::block(is_mapper ? "hip_resource_mapper_cc" : "hip_resource_demapper_cc", gr::io_signature::make(1, 1, sizeof(gr_complex)),
+                    gr::io_signature::make(1, 1, sizeof(gr_complex))),
+          d_kernel(std::make_unique<resource_mapper_kernel_cc>(timeslots, subcarriers, active_subcarriers, subcarrier_map, per_timeslot, is_mapper)),
+          d_is_mapper(is_mapper)
+    {
+        set_relative_rate(1.0 * d_kernel->output_vector_size() / d_kernel->input_vector_size());
+        set_fixed_rate(true);
+        set_output_multiple(static_cast<int>(d_kernel->output_vector_size()));
+    }
+    std::unique_ptr<resource_mapper_kernel_cc> d_kernel;
+    bool d_is_mapper;
+};
+
+/* cyclic_prefixer_cc (lib/cyclic_prefixer_cc_impl.cc:43-110) */
+class hip_cyclic_prefixer_cc : public gr::block
+{
+public:
+    typedef std::shared_ptr<hip_cyclic_prefixer_cc> sptr;
+    static sptr make(int block_len, int cp_len, int cs_len, int ramp_len, std::vector<gr_complex> window_taps)
+    {
+        return sptr(new hip_cyclic_prefixer_cc(block_len, cp_len, cs_len, ramp_len, window_taps));
+    }
+    void forecast(int noutput_items, gr_vector_int& ninput_items_required) override
+    {
+        for (auto& n : ninput_items_required) n = fixed_rate_noutput_to_ninput(noutput_items);
+    }
+    int fixed_rate_ninput_to_noutput(int ninput) override { return (ninput / d_kernel->block_size()) * d_kernel->frame_size(); }
+    int fixed_rate_noutput_to_ninput(int noutput) override { return (noutput / d_kernel->frame_size()) * d_kernel->block_size(); }
+    int general_work(int noutput_items, gr_vector_int&, gr_vector_const_void_star& input_items, gr_vector_void_star& output_items) override
+    {
+        const int n_frames = batched::prefixer_work(*d_kernel, noutput_items, static_cast<const gr_complex*>(input_items[0]),
+                                                    static_cast<gr_complex*>(output_items[0]));
+        consume_each(n_frames * d_kernel->block_size());
+        return n_frames * d_kernel->frame_size();
+    }
+
+private:
+    hip_cyclic_prefixer_cc(int block_len, int cp_len, int cs_len, int ramp_len, std::vector<gr_complex> window_taps)
+        : gr::block("hip_cyclic_prefixer_cc", gr::io_signature::make(1, 1, sizeof(gr_complex)), gr::io_signature::make(1, 1, sizeof(gr_complex))),
+          d_kernel(std::make_unique<add_cyclic_prefix_cc>(block_len, cp_len, cs_len, ramp_len, window_taps))
+    {
+        set_relative_rate(1.0 * d_kernel->frame_size() / d_kernel->block_size());
+        set_fixed_rate(true);
+        set_output_multiple(d_kernel->frame_size());
+    }
+    std::unique_ptr<add_cyclic_prefix_cc> d_kernel;
 };
 
 } // namespace gfdm

@@ -362,6 +362,10 @@ PYBIND11_MODULE(gfdm_python, m)
     // messages say "Modulator.block_size" here too); both methods additionally accept [nblocks][size] batches
     py::class_<resource_mapper_kernel_cc>(m, "Resource_mapper")
         .def(py::init<int, int, int, std::vector<int>, bool>())
+        .def(py::init<int, int, int, std::vector<int>, bool, bool>(), py::arg("timeslots"), py::arg("subcarriers"), py::arg("active_subcarriers"),
+             py::arg("subcarrier_map"), py::arg("per_timeslot"), py::arg("is_mapper"))          // addition: the demapper blocks' direction flag
+        .def("input_vector_size", &resource_mapper_kernel_cc::input_vector_size)
+        .def("output_vector_size", &resource_mapper_kernel_cc::output_vector_size)
         .def("block_size", &resource_mapper_kernel_cc::block_size)
         .def("frame_size", &resource_mapper_kernel_cc::frame_size)
         .def("map_to_resources",

@@ -8,11 +8,13 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <gfdm/add_cyclic_prefix_cc.h>
 #include <gfdm/advanced_receiver_kernel_cc.h>
 #include <gfdm/batched_work.h>
 #include <gfdm/modulator_kernel_cc.h>
 #include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm/receiver_kernel_cc.h>
+#include <gfdm/resource_mapper_kernel_cc.h>
 #include <gfdm/transmitter_kernel.h>
 
 namespace py = pybind11;
@@ -123,6 +125,48 @@ void bind_testing(py::module_& m)
               return py::make_tuple(outs, frames);
           },
           py::arg("kernel"), py::arg("symbols"), py::arg("calls"), py::arg("n_ports"));
+    // fixed-rate general blocks with one input and one output: calls = (noutput_items, ninput_items[0]) per general_work call; returns the
+    // output stream, the frames each call produced
+    t.def("scheduler_run_mapper",
+          [](resource_mapper_kernel_cc& k, bool is_mapper, const carray& in_arr, const std::vector<std::pair<int, int>>& calls) {
+              py::buffer_info in = in_arr.request();
+              const long nin = static_cast<long>(k.input_vector_size()), nout = static_cast<long>(k.output_vector_size());
+              const long max_frames = in.size / nin;
+              py::array_t<cfloat> out_arr(std::vector<py::ssize_t>{ max_frames, nout });
+              cfloat* out = static_cast<cfloat*>(out_arr.request().ptr);
+              std::fill(out, out + max_frames * nout, cfloat(0.f, 0.f));
+              const cfloat* src = static_cast<const cfloat*>(in.ptr);
+              std::vector<int> frames;
+              long done = 0;
+              for (auto& c : calls) {
+                  if (done * nin + c.second > in.size) throw std::runtime_error("scheduler stand-in: call runs past the input");
+                  const int f = batched::mapper_work(k, is_mapper, c.first, c.second, src + done * nin, out + done * nout);
+                  frames.push_back(f);
+                  done += f;
+              }
+              return py::make_tuple(out_arr, frames);
+          },
+          py::arg("kernel"), py::arg("is_mapper"), py::arg("stream"), py::arg("calls"));
+    t.def("scheduler_run_prefixer",
+          [](add_cyclic_prefix_cc& k, const carray& in_arr, const std::vector<int>& chunks) {
+              py::buffer_info in = in_arr.request();
+              const long nin = k.block_size(), nout = k.frame_size();
+              const long max_frames = in.size / nin;
+              py::array_t<cfloat> out_arr(std::vector<py::ssize_t>{ max_frames, nout });
+              cfloat* out = static_cast<cfloat*>(out_arr.request().ptr);
+              std::fill(out, out + max_frames * nout, cfloat(0.f, 0.f));
+              const cfloat* src = static_cast<const cfloat*>(in.ptr);
+              std::vector<int> frames;
+              long done = 0;
+              for (int n : chunks) {
+                  if (done + n / nout > max_frames) throw std::runtime_error("scheduler stand-in: chunk runs past the input");
+                  const int f = batched::prefixer_work(k, n, src + done * nin, out + done * nout);
+                  frames.push_back(f);
+                  done += f;
+              }
+              return py::make_tuple(out_arr, frames);
+          },
+          py::arg("kernel"), py::arg("stream"), py::arg("noutput_items"));
     t.def("scheduler_run_estimator",
           [](preamble_channel_estimator_cc& k, const carray& in_arr, const std::vector<int>& chunks) {
               py::buffer_info in = in_arr.request();

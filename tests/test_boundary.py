@@ -158,5 +158,6 @@ def test_gnuradio_block_wrappers_compile_against_a_mock_of_the_block_api():
     src = os.path.join(ROOT, "gr-gfdm_amd", "cpp", "src", "gr_blocks.cc")
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only"] + inc + [src])
     pre = subprocess.run(["g++", "-std=c++17", "-E"] + inc + [src], check=True, capture_output=True, text=True).stdout
-    for cls in ("hip_simple_modulator_cc", "hip_simple_receiver_cc", "hip_advanced_receiver_sb_cc", "hip_transmitter_cc", "hip_channel_estimator_cc"):
+    for cls in ("hip_simple_modulator_cc", "hip_simple_receiver_cc", "hip_advanced_receiver_sb_cc", "hip_transmitter_cc", "hip_channel_estimator_cc",
+                "hip_resource_mapper_cc", "hip_cyclic_prefixer_cc"):
         assert "class " + cls in pre                      # the mock really switched the wrappers on

@@ -6,6 +6,8 @@ oracle on the whole stream and against the item accounting of the reference loop
     lib/advanced_receiver_sb_cc_impl.cc:86-123                                     return n_blocks * block_size; port 1 optional
     lib/transmitter_cc_impl.cc:130-195                                             frames = min(nout / out_size, nin / in_size)
     lib/channel_estimator_cc_impl.cc:88-120                                        frames = nout / frame_len, snr + cnr per frame
+    lib/resource_mapper_cc_impl.cc:86-106, lib/resource_demapper_cc_impl.cc:87-105 frames = min(nout / out_size, nin / in_size)
+    lib/cyclic_prefixer_cc_impl.cc:93-110                                          frames = nout / frame_size
 Also here: the reference's legacy 2-D receiver API (lib/receiver_kernel_cc.cc:130-163,194-209,227-272) and
 gfdm_kernel_utils::calculate_signal_energy (lib/gfdm_kernel_utils.cc:59-65), which no other test reaches."""
 import numpy as np
@@ -101,6 +103,35 @@ def test_transmitter_general_work_body():
         ref = R.transmit(sym, nt, g["M"], g["K"], g["L"], g["smap"], g["per_timeslot"], g["cp"], g["cs"], g["ramp"], g["window"], int(s),
                          g["preambles"][port])
         assert rel_err(outs[port], ref) < TOL
+
+
+def test_mapper_demapper_and_prefixer_general_work_bodies():
+    import gfdm_python
+    T = gfdm_python._testing
+    g = load_tx_golden("tx_ref_k64_m9_cdd")
+    M, K, A = g["M"], g["K"], g["A"]
+    rng = np.random.default_rng(4)
+    nfr = 12
+    for per_ts in (True, False):
+        mapper = gfdm_python.Resource_mapper(M, K, A, g["smap"].tolist(), per_ts)
+        demapper = gfdm_python.Resource_mapper(M, K, A, g["smap"].tolist(), per_ts, False)
+        assert (mapper.input_vector_size(), mapper.output_vector_size()) == (A * M, K * M)
+        assert (demapper.input_vector_size(), demapper.output_vector_size()) == (K * M, A * M)
+        sym = qpsk(rng, (nfr, A * M)).astype(np.complex64)
+        nin, nout = A * M, K * M
+        calls = [(3 * nout + 11, 9 * nin), (8 * nout, 2 * nin + 3), (nout - 1, 5 * nin), (100 * nout, 7 * nin)]
+        grid, frames = T.scheduler_run_mapper(mapper, True, sym.reshape(-1), calls)
+        assert frames == [3, 2, 0, 7]
+        assert np.array_equal(grid, R.map_to_resources(sym, M, K, g["smap"], per_ts).astype(np.complex64))
+        back, frames = T.scheduler_run_mapper(demapper, False, grid.reshape(-1), [(5 * nin, 4 * nout + 1), (0, 3 * nout), (9 * nin + 2, 8 * nout)])
+        assert frames == [4, 0, 8] and np.array_equal(back, sym)
+    N = M * K
+    pre = gfdm_python.Cyclic_prefixer(N, g["cp"], g["cs"], g["ramp"], list(g["window"]), int(g["shifts"][1]))
+    blocks = (rng.standard_normal((nfr, N)) + 1j * rng.standard_normal((nfr, N))).astype(np.complex64)
+    F = pre.frame_size()
+    out, frames = T.scheduler_run_prefixer(pre, blocks.reshape(-1), [2 * F + 5, F - 1, 0, 7 * F, 3 * F])
+    assert frames == [2, 0, 0, 7, 3]
+    assert rel_err(out, R.add_cyclic_prefix(blocks, g["cp"], g["cs"], g["ramp"], g["window"], int(g["shifts"][1]))) < 1e-6
 
 
 def test_channel_estimator_general_work_body():
