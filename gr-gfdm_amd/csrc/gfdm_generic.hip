@@ -228,15 +228,29 @@ __device__ void emit_demapped(cf* o, const cf* tile, const RxIo& io, int K, int 
     }
 }
 
-__global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan pg, TxParams tx, int tab_off, cf* __restrict__ out, const cf* __restrict__ in)
+// Blocks too large for the tiles to sit in LDS (16 N bytes above the CU's 160 KiB, i.e. N > ~10 000) run the SAME kernels with the
+// tiles in a global scratch buffer, one slice per workgroup (GLOBAL = true; only the reduction scratch and the root tables stay in
+// LDS).  The tiles are private to the workgroup, so the workgroup barrier orders them exactly as it orders LDS (all waves of a
+// workgroup share the CU's vector L1).  Slow, but every shape the reference accepts works.  TileArgs: slice base, slice length,
+// first GFDM block of this launch (a long batch goes down in chunks that share one scratch buffer).
+struct TileArgs {
+    cf* gtiles;
+    int64_t tile_elems;
+    int64_t blk0;
+};
+
+template <bool GLOBAL>
+__global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan pg, TxParams tx, int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ in)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevicePlan p = stage_tables(pg, smem, tab_off);
-    cf* t0 = reinterpret_cast<cf*>(smem);
+    cf* t0;
+    if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem);
     cf* t1 = t0 + p.N;
     const int M = p.M, K = p.K, L = p.L, N = p.N;
-    const cf* x = in + (int64_t)blockIdx.x * (tx.mapped ? tx.nin : N);
-    cf* o = out + (int64_t)blockIdx.x * N;
+    const int64_t blk = ta.blk0 + blockIdx.x;
+    const cf* x = in + blk * (tx.mapped ? tx.nin : N);
+    cf* o = out + blk * N;
 
     if (tx.mapped) {                                               // resource mapper fused into the load (gfdm_tx.h)
         for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = tx_symbol(tx, x, M, idx / M, idx % M);
@@ -281,10 +295,10 @@ __global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan pg, TxParams
             if (e >= M) e -= M;
         }
         const cf y = make_float2(acc.x * scale, acc.y * scale);
-        if (tx.framed) tx_store_sample(tx, blockIdx.x, N, idx, y);      // cyclic prefix / suffix + ramp, every port
+        if (tx.framed) tx_store_sample(tx, blk, N, idx, y);             // cyclic prefix / suffix + ramp, every port
         else o[idx] = y;
     }
-    if (tx.framed) tx_store_preamble(tx, blockIdx.x, threadIdx.x, GT);
+    if (tx.framed) tx_store_preamble(tx, blk, threadIdx.x, GT);
 }
 
 // transmitter_kernel::add_frame on an already modulated block
@@ -295,24 +309,28 @@ __global__ __launch_bounds__(GT) void k_add_frame(DevicePlan p, TxParams tx, con
     tx_store_preamble(tx, blockIdx.x, threadIdx.x, GT);
 }
 
+template <bool GLOBAL>
 __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams ic, EstPlan est, int eq_source, int ntiles, int mode, int s_in_global,
-                                                        int tab_off, cf* __restrict__ out, const cf* __restrict__ in, const cf* __restrict__ f_eq)
+                                                        int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ in,
+                                                        const cf* __restrict__ f_eq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevicePlan p = stage_tables(pg, smem, tab_off);
     float* red = reinterpret_cast<float*>(smem);
-    cf* t0 = reinterpret_cast<cf*>(smem + RED_BYTES);
+    cf* t0;
+    if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem + RED_BYTES);
     cf* t1 = t0 + p.N;
     cf* t2 = t1 + p.N;                                             // only valid when 3 tiles were requested
     const int M = p.M, K = p.K, L = p.L, N = p.N;
-    const cf* x = in + (int64_t)blockIdx.x * (int64_t)(ic.io.in_stride ? ic.io.in_stride : N) + ic.io.in_offset;   // frame -> block
+    const int64_t blk = ta.blk0 + blockIdx.x;
+    const cf* x = in + blk * (int64_t)(ic.io.in_stride ? ic.io.in_stride : N) + ic.io.in_offset;   // frame -> block
     const bool demap = ic.io.demap && mode != RX_FD;
-    cf* o = out + (int64_t)blockIdx.x * (demap ? ic.io.nout : N);
-    const cf* eq = (eq_source == EQ_VECTOR) ? f_eq + (int64_t)blockIdx.x * N : nullptr;
+    cf* o = out + blk * (demap ? ic.io.nout : N);
+    const cf* eq = (eq_source == EQ_VECTOR) ? f_eq + blk * N : nullptr;
     cf* filt = t0 + (size_t)ntiles * N + K;                       // EQ_PREAMBLE: smoothed channel estimate, behind the tiles
     if (eq_source == EQ_PREAMBLE) {                                // channel estimator in front, the tiles are its scratch
         cf* bins = t0 + (size_t)ntiles * N;
-        estimate_preamble_bins(est, f_eq + (int64_t)blockIdx.x * (est.pre_stride ? est.pre_stride : 2 * K), t0, t1, bins);
+        estimate_preamble_bins(est, f_eq + blk * (est.pre_stride ? est.pre_stride : 2 * K), t0, t1, bins);
         __syncthreads();
         for (int i = threadIdx.x; i < est.n_est; i += GT) filt[i] = est_filter_bin(bins, i, est);
         __syncthreads();
@@ -460,27 +478,33 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams 
     }
 }
 
-__global__ __launch_bounds__(GT) void k_generic_to_td(DevicePlan pg, int tab_off, cf* __restrict__ out, const cf* __restrict__ in)
+template <bool GLOBAL>
+__global__ __launch_bounds__(GT) void k_generic_to_td(DevicePlan pg, int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ in)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevicePlan p = stage_tables(pg, smem, tab_off);
-    cf* t0 = reinterpret_cast<cf*>(smem);
-    const cf* x = in + (int64_t)blockIdx.x * p.N;
+    cf* t0;
+    if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem);
+    const int64_t blk = ta.blk0 + blockIdx.x;
+    const cf* x = in + blk * p.N;
     for (int idx = threadIdx.x; idx < p.N; idx += GT) t0[idx] = x[idx];
     __syncthreads();
-    row_dft<true>(out + (int64_t)blockIdx.x * p.N, t0, p.K, p.M, p.M, 1, p.wM, 1.f / (float)p.M);
+    row_dft<true>(out + blk * p.N, t0, p.K, p.M, p.M, 1, p.wM, 1.f / (float)p.M);
 }
 
-__global__ __launch_bounds__(GT) void k_generic_cancel(DevicePlan pg, int tab_off, cf* __restrict__ out, const cf* __restrict__ td,
+template <bool GLOBAL>
+__global__ __launch_bounds__(GT) void k_generic_cancel(DevicePlan pg, int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ td,
                                                        const cf* __restrict__ fd)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevicePlan p = stage_tables(pg, smem, tab_off);
-    cf* t0 = reinterpret_cast<cf*>(smem);
-    const cf* x = td + (int64_t)blockIdx.x * p.N;
+    cf* t0;
+    if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem);
+    const int64_t blk = ta.blk0 + blockIdx.x;
+    const cf* x = td + blk * p.N;
     for (int idx = threadIdx.x; idx < p.N; idx += GT) t0[idx] = x[idx];
     __syncthreads();
-    cancel_rows(out + (int64_t)blockIdx.x * p.N, t0, fd + (int64_t)blockIdx.x * p.N, p);
+    cancel_rows(out + blk * p.N, t0, fd + blk * p.N, p);
 }
 
 
@@ -595,17 +619,56 @@ size_t generic_lds_bytes(int N, int ntiles) { return (size_t)ntiles * (size_t)N 
 // ... plus the W_M and W_K tables behind everything else
 static size_t table_bytes(const DevicePlan& p) { return (((size_t)(2 * p.M + p.K) * sizeof(cf)) + 15) & ~(size_t)15; }
 
-// one_tile: only the single-tile kernels (to_td, cancel) have to fit
-bool generic_supports(int M, int K, bool one_tile) { return generic_lds_bytes(M * K, one_tile ? 1 : 2) + (size_t)(2 * M + K + 2) * sizeof(cf) <= LDS_MAX; }
+// Blocks whose tiles fit the LDS of a CU use it; larger ones take the global-scratch form of the same kernels (GLOBAL), bounded only by
+// the root tables that always sit in LDS.  one_tile is kept for the callers' sake: both forms exist for every kernel.
+bool generic_supports(int M, int K, bool one_tile)
+{
+    (void)one_tile;
+    return M >= 1 && K >= 1 && (int64_t)M * K <= ((int64_t)1 << 24) && RED_BYTES + (size_t)(2 * M + K + 2) * sizeof(cf) + 64 <= LDS_MAX;
+}
+
+namespace {
+
+// scratch slices for a launch of the GLOBAL kernels: at most ~256 MiB, so a long batch goes down in chunks; allocated and freed in
+// stream order (no handle state: calls on different streams do not share it)
+struct Scratch {
+    cf* base = nullptr;
+    int64_t chunk = 0;
+    hipStream_t stream = nullptr;
+    hipError_t open(int64_t tile_elems, int64_t nblocks, hipStream_t s)
+    {
+        stream = s;
+        const int64_t bytes_per_block = tile_elems * (int64_t)sizeof(cf);
+        chunk = std::max<int64_t>(64, ((int64_t)256 << 20) / bytes_per_block);
+        if (chunk > nblocks) chunk = nblocks;
+        return hipMallocAsync(reinterpret_cast<void**>(&base), (size_t)(chunk * bytes_per_block), s);
+    }
+    hipError_t close() { return base ? hipFreeAsync(base, stream) : hipSuccess; }
+};
+
+}  // namespace
 
 hipError_t launch_generic_modulate(const DevicePlan& p, const TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
     const size_t tab = generic_lds_bytes(p.N, 2), lds = tab + table_bytes(p);
-    hipError_t e = allow_lds(k_generic_modulate, lds);
+    if (lds <= LDS_MAX) {
+        hipError_t e = allow_lds(k_generic_modulate<false>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_generic_modulate<false>, dim3((unsigned)nblocks), dim3(GT), lds, s, p, tx, (int)tab, TileArgs{ nullptr, 0, 0 }, out, in);
+        return hipGetLastError();
+    }
+    Scratch sc;
+    const int64_t tile_elems = 2 * (int64_t)p.N;
+    hipError_t e = sc.open(tile_elems, nblocks, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_generic_modulate, dim3((unsigned)nblocks), dim3(GT), lds, s, p, tx, (int)tab, out, in);
-    return hipGetLastError();
+    for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
+        const int64_t n = std::min(sc.chunk, nblocks - b0);
+        hipLaunchKernelGGL(k_generic_modulate<true>, dim3((unsigned)n), dim3(GT), table_bytes(p), s, p, tx, 0, TileArgs{ sc.base, tile_elems, b0 }, out, in);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = sc.close();
+    return e != hipSuccess ? e : e2;
 }
 
 hipError_t launch_add_frame(const DevicePlan& p, const TxParams& tx, const cf* in, int64_t nblocks, hipStream_t s)
@@ -622,39 +685,80 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const
     const int eq_source = est ? EQ_PREAMBLE : f_eq ? EQ_VECTOR : EQ_NONE;
     if (est && p.M < 2) return hipErrorInvalidConfiguration;               // the tiles double as the estimator's 2K scratch
     const size_t extra = est ? (size_t)(2 * p.K + 2) * sizeof(cf) : 0;     // K-bin estimate + smoothed estimate
-    int ntiles = 2, s_in_global = 0;
-    if (mode == RX_IC && ic.ic_iter > 0) {
-        if (generic_lds_bytes(p.N, 3) + extra + table_bytes(p) <= LDS_MAX) ntiles = 3; else s_in_global = 1;
-    }
-    if (s_in_global && ic.io.demap) return hipErrorInvalidConfiguration;   // the demapped output block is too small to park S in
-    const size_t tab = (generic_lds_bytes(p.N, ntiles) + extra + 15) & ~(size_t)15, lds = tab + table_bytes(p);
-    if (lds > LDS_MAX) return hipErrorInvalidConfiguration;
-    hipError_t e = allow_lds(k_generic_receive, lds);
-    if (e != hipSuccess) return e;
     static const EstPlan kNoEst = {};
-    hipLaunchKernelGGL(k_generic_receive, dim3((unsigned)nblocks), dim3(GT), lds, s, p, ic, est ? *est : kNoEst, eq_source, ntiles, mode, s_in_global,
-                       (int)tab, out, in, f_eq);
-    return hipGetLastError();
+    const bool ic_rounds = (mode == RX_IC && ic.ic_iter > 0);
+    if (generic_lds_bytes(p.N, 2) + extra + table_bytes(p) <= LDS_MAX) {
+        int ntiles = 2, s_in_global = 0;
+        if (ic_rounds) {
+            if (generic_lds_bytes(p.N, 3) + extra + table_bytes(p) <= LDS_MAX) ntiles = 3; else s_in_global = 1;
+        }
+        if (!(s_in_global && ic.io.demap)) {                               // (a demapped output block is too small to park S in: GLOBAL below)
+            const size_t tab = (generic_lds_bytes(p.N, ntiles) + extra + 15) & ~(size_t)15, lds = tab + table_bytes(p);
+            hipError_t e = allow_lds(k_generic_receive<false>, lds);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_generic_receive<false>, dim3((unsigned)nblocks), dim3(GT), lds, s, p, ic, est ? *est : kNoEst, eq_source, ntiles, mode,
+                               s_in_global, (int)tab, TileArgs{ nullptr, 0, 0 }, out, in, f_eq);
+            return hipGetLastError();
+        }
+    }
+    Scratch sc;
+    const int ntiles = ic_rounds ? 3 : 2;
+    const int64_t tile_elems = (int64_t)ntiles * p.N + 2 * p.K + 2;
+    hipError_t e = sc.open(tile_elems, nblocks, s);
+    if (e != hipSuccess) return e;
+    const size_t tab = (RED_BYTES + 15) & ~(size_t)15;
+    for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
+        const int64_t n = std::min(sc.chunk, nblocks - b0);
+        hipLaunchKernelGGL(k_generic_receive<true>, dim3((unsigned)n), dim3(GT), tab + table_bytes(p), s, p, ic, est ? *est : kNoEst, eq_source, ntiles,
+                           mode, 0, (int)tab, TileArgs{ sc.base, tile_elems, b0 }, out, in, f_eq);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = sc.close();
+    return e != hipSuccess ? e : e2;
 }
 
 hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
     const size_t tab = generic_lds_bytes(p.N, 1), lds = tab + table_bytes(p);
-    hipError_t e = allow_lds(k_generic_to_td, lds);
+    if (lds <= LDS_MAX) {
+        hipError_t e = allow_lds(k_generic_to_td<false>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_generic_to_td<false>, dim3((unsigned)nblocks), dim3(GT), lds, s, p, (int)tab, TileArgs{ nullptr, 0, 0 }, out, in);
+        return hipGetLastError();
+    }
+    Scratch sc;
+    hipError_t e = sc.open(p.N, nblocks, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_generic_to_td, dim3((unsigned)nblocks), dim3(GT), lds, s, p, (int)tab, out, in);
-    return hipGetLastError();
+    for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
+        const int64_t n = std::min(sc.chunk, nblocks - b0);
+        hipLaunchKernelGGL(k_generic_to_td<true>, dim3((unsigned)n), dim3(GT), table_bytes(p), s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0 }, out, in);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = sc.close();
+    return e != hipSuccess ? e : e2;
 }
 
 hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, const cf* fd, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
     const size_t tab = generic_lds_bytes(p.N, 1), lds = tab + table_bytes(p);
-    hipError_t e = allow_lds(k_generic_cancel, lds);
+    if (lds <= LDS_MAX) {
+        hipError_t e = allow_lds(k_generic_cancel<false>, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_generic_cancel<false>, dim3((unsigned)nblocks), dim3(GT), lds, s, p, (int)tab, TileArgs{ nullptr, 0, 0 }, out, td, fd);
+        return hipGetLastError();
+    }
+    Scratch sc;
+    hipError_t e = sc.open(p.N, nblocks, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_generic_cancel, dim3((unsigned)nblocks), dim3(GT), lds, s, p, (int)tab, out, td, fd);
-    return hipGetLastError();
+    for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
+        const int64_t n = std::min(sc.chunk, nblocks - b0);
+        hipLaunchKernelGGL(k_generic_cancel<true>, dim3((unsigned)n), dim3(GT), table_bytes(p), s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0 }, out, td, fd);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = sc.close();
+    return e != hipSuccess ? e : e2;
 }
 
 size_t estimator_lds_bytes(int K) { return (size_t)(6 * K + 1) * sizeof(cf); }   // two [K][2] tiles, K-bin estimate, smoothed estimate

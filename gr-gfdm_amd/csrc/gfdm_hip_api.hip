@@ -225,7 +225,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : pl.family == gfdm::FAMILY_ROWLANE_JIT ? "rowlane_jit" : "generic_lds";
     // the generic family holds two tiles of the block in LDS; handles on the row-lane families only use it for the stand-alone
     // transform_subcarriers_to_td / cancel_sc_interference entry points (one tile)
-    if (!gfdm::generic_supports(M, K, pl.family != gfdm::FAMILY_GENERIC)) return fail(GFDM_HIP_EUNSUPPORTED, "block (timeslots*subcarriers) does not fit LDS");
+    if (!gfdm::generic_supports(M, K, pl.family != gfdm::FAMILY_GENERIC)) return fail(GFDM_HIP_EUNSUPPORTED, "root tables (2 * timeslots + subcarriers values) do not fit LDS");
     return GFDM_HIP_OK;
 }
 

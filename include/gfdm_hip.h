@@ -42,7 +42,7 @@ typedef enum gfdm_hip_status {
     GFDM_HIP_ENODEV = -4,          /* no usable HIP device */
     GFDM_HIP_EHIP = -5,            /* a HIP runtime call failed */
     GFDM_HIP_ENOMEM = -6,
-    GFDM_HIP_EUNSUPPORTED = -7     /* block does not fit the device (LDS) */
+    GFDM_HIP_EUNSUPPORTED = -7     /* beyond the device: timeslots * subcarriers > 2^24, or 2 * timeslots + subcarriers above ~20 000 */
 } gfdm_hip_status;
 
 /* how hard decisions are taken in the IC loop (gr::digital::constellation::decision_maker,

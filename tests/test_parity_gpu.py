@@ -621,3 +621,65 @@ def test_handles_on_concurrent_host_threads():
     assert not errors, errors
     for a, b in zip(serial, results):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("M,K,L", [(15, 1024, 2), (33, 512, 2), (5, 4096, 4)])
+def test_blocks_larger_than_the_lds(M, K, L):
+    """Blocks whose tiles do not fit the 160 KiB of a CU (N > ~10 000: K = 1024 x M = 15 ...) run the generic kernels with their tiles
+    in a global scratch buffer: every entry point against the oracle, frames / demapper, the fused transmitter, and a batch long
+    enough to go down in several chunks of the scratch buffer."""
+    import torch
+    import gfdm_amd
+    rng = np.random.default_rng(M + K)
+    N, B = M * K, 3
+    taps = get_frequency_domain_filter("rrc", 0.3, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    A = K - K // 8
+    smap = np.concatenate((np.arange(1, A // 2 + 1), np.arange(K - A // 2, K)))
+    mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, 2, R.qpsk_points())
+    assert (mod.kernel_name(), dem.kernel_name(), adv.kernel_name()) == ("generic_lds",) * 3
+    d = np.zeros((B, K, M), complex)
+    d[:, smap, :] = qpsk(rng, (B, A, M))
+    d = d.reshape(B, N)
+    x = R.modulate(d, nt, M, K, L)
+    assert rel_err(mod.modulate(d), x) < TOL
+    feq = np.fft.fft(np.array([1, .4 - .2j, .1j]), N)[None, :] * np.exp(0.02j * np.arange(B))[:, None]
+    xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
+    S = R.fft_filter_downsample(x, nt, M, K, L)
+    assert rel_err(dem.fft_filter_downsample(x), S) < TOL
+    assert rel_err(dem.demodulate(x), R.demodulate(x, nt, M, K, L)) < TOL
+    assert rel_err(dem.demodulate_equalize(xe, feq), R.demodulate(xe, nt, M, K, L, feq)) < TOL
+    td = R.transform_subcarriers_to_td(S, M, K)
+    assert rel_err(dem.transform_subcarriers_to_td(S), td) < TOL
+    assert rel_err(dem.cancel_sc_interference(d, S), R.cancel_sc_interference(d, S, R.ic_filter_taps(nt, M, L), M, K)) < TOL
+    ref, st = R.advanced_receive(xe, nt, M, K, L, smap, R.qpsk_points(), 2, f_eq=feq, kind="qpsk", return_stages=True)
+    keep = guarded(st, smap, K, M)
+    got = adv.demodulate_equalize(xe, feq)
+    assert keep.any() and rel_err(got[keep], ref[keep]) < TOL
+    # frames in, demapped symbols out, with IC (the combination that has no LDS form even for mid-sized blocks)
+    adv.configure_frames(N + 9, 4, smap, True)
+    frames = rng.standard_normal((B, N + 9)) + 1j * rng.standard_normal((B, N + 9))
+    frames[:, 4:4 + N] = xe
+    assert rel_err(adv.demodulate_frames(frames, feq)[keep], R.demap_from_resources(ref, M, K, smap, True)[keep]) < TOL
+    # fused transmitter (mapper in front, prefix + preamble behind)
+    window = np.ones(N + 24 + 8, complex)
+    pre = rng.standard_normal(16) + 1j * rng.standard_normal(16)
+    tx = gfdm_amd.Transmitter(M, K, A, 24, 8, 0, smap, True, L, taps, window, [0, 5], [pre, pre])
+    sym = qpsk(rng, (B, A * M))
+    outs = tx.transmit(sym)
+    for port, s in enumerate((0, 5)):
+        assert rel_err(outs[port], R.transmit(sym, nt, M, K, L, smap, True, 24, 8, 0, window, s, pre)) < TOL
+    # a batch that needs several chunks of the scratch buffer: five distinct blocks repeated, outputs must repeat exactly
+    nb = int((256 << 20) // (3 * N * 8)) + 70
+    dev = torch.device("cuda:0")
+    base = torch.tensor(xe[:3].astype(np.complex64), device=dev)
+    big = base.repeat((nb + 2) // 3, 1)[:nb].contiguous()
+    big_eq = torch.tensor(feq[:3].astype(np.complex64), device=dev).repeat((nb + 2) // 3, 1)[:nb].contiguous()
+    adv2 = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, 2, R.qpsk_points())
+    out = adv2.demodulate_equalize(big, big_eq)
+    torch.cuda.synchronize()
+    first = out[:3]
+    for b in (3, nb // 2 // 3 * 3, (nb - 3) // 3 * 3):
+        assert torch.equal(out[b:b + 3], first)
+    assert rel_err(first.cpu().numpy()[keep], ref[keep]) < TOL
