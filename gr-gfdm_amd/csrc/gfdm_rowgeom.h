@@ -12,7 +12,7 @@
 namespace gfdm {
 namespace rowgeom {
 
-// Subcarrier counts the family covers: powers of two 4 .. 512 (radix-4 / wide passes, gfdm_rowlane_impl.h) and any other
+// Subcarrier counts the family covers: powers of two 4 .. 1024 (radix-4 / wide passes, gfdm_rowlane_impl.h) and any other
 // K = R0 * R1 <= 256 with both factors <= 16 (two Stockham passes with the codelets Dft<R0>, Dft<R1>; R0 = 1: a single pass).
 constexpr bool pow2(int K) { return K > 0 && (K & (K - 1)) == 0; }
 constexpr int mixed_r1(int K)                                                // radix of the LAST pass: the largest divisor <= 16
@@ -24,7 +24,7 @@ constexpr int mixed_r1(int K)                                                // 
 }
 constexpr int mixed_r0(int K) { return K / mixed_r1(K); }
 constexpr bool mixed(int K) { return !pow2(K) && K >= 3 && K <= 256 && mixed_r0(K) <= 16; }
-constexpr bool supported(int K) { return (pow2(K) && K >= 4 && K <= 512) || mixed(K); }
+constexpr bool supported(int K) { return (pow2(K) && K >= 4 && K <= 1024) || mixed(K); }
 
 // threads per workgroup: whole blocks only (a block never straddles two workgroups)
 constexpr int wg(int K) { return K >= 128 ? K : pow2(K) ? GFDM_ROW_WG : (GFDM_ROW_WG / K) * K; }

@@ -72,11 +72,11 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #endif
 
 template <int K> struct RowShape {
-    static_assert(rowgeom::supported(K), "row-lane family: K a power of two 4 .. 512, or K = R0 * R1 <= 256 with both factors <= 16");
+    static_assert(rowgeom::supported(K), "row-lane family: K a power of two 4 .. 1024, or K = R0 * R1 <= 256 with both factors <= 16");
     // K not a power of two: two Stockham passes of radix R0 and R1 (R0 = 1: one pass), lds_subcarrier_fft2
     static constexpr bool MIXED = rowgeom::mixed(K);
     static constexpr int R0 = MIXED ? rowgeom::mixed_r0(K) : 1, R1 = MIXED ? rowgeom::mixed_r1(K) : 1;
-    static constexpr int log2K = (K == 4) ? 2 : (K == 8) ? 3 : (K == 16) ? 4 : (K == 32) ? 5 : (K == 64) ? 6 : (K == 128) ? 7 : (K == 256) ? 8 : (K == 512) ? 9 : 0;
+    static constexpr int log2K = (K == 4) ? 2 : (K == 8) ? 3 : (K == 16) ? 4 : (K == 32) ? 5 : (K == 64) ? 6 : (K == 128) ? 7 : (K == 256) ? 8 : (K == 512) ? 9 : (K == 1024) ? 10 : 0;
     static constexpr int NP4 = log2K / 2;
     static constexpr bool HAS2 = (log2K & 1) != 0;
     static constexpr int WG = rowgeom::wg(K);              // threads per workgroup (blocks of K <= 64 lanes are packed)
@@ -96,9 +96,12 @@ template <int K> struct RowShape {
 #else
     static constexpr bool RADIX8X16 = false;
 #endif
-    static constexpr bool WIDE = RADIX16 || RADIX8X16 || MIXED;   // FftTwiddles holds the R0 - 1 twiddles of the first wide pass
-    static constexpr int WIDE_R0 = RADIX16 ? 16 : RADIX8X16 ? 8 : MIXED ? R0 : 1;
-    static constexpr int WIDE_R1 = (RADIX16 || RADIX8X16) ? 16 : MIXED ? R1 : 1;
+    // K = 512 = 8 x 8 x 8, K = 1024 = 8 x 8 x 16: THREE wide passes (lds_subcarrier_fft3) instead of four or five radix-4 / radix-2 passes
+    static constexpr bool WIDE3 = (K == 512 || K == 1024);
+    static constexpr bool WIDE = RADIX16 || RADIX8X16 || MIXED || WIDE3;   // FftTwiddles holds the twiddles of the wide passes
+    static constexpr int WIDE_R0 = (RADIX16 ? 16 : RADIX8X16 ? 8 : MIXED ? R0 : WIDE3 ? 8 : 1);
+    static constexpr int WIDE_R1 = (RADIX16 || RADIX8X16) ? 16 : MIXED ? R1 : WIDE3 ? 8 : 1;
+    static constexpr int WIDE_R2 = WIDE3 ? K / 64 : 1;
 };
 
 // x mod K for 0 <= x (row and twiddle indices): a mask where K is a power of two, a constant division otherwise
@@ -159,7 +162,7 @@ template <int K> struct FftLayout {
             // radix-16 passes: 16 neighbouring lanes touch rows tq + 16 r (reads, phase A), 16 tq + u (pass-0 writes); rotating the
             // low four row bits by the next four keeps the slots of both patterns distinct mod 32 (b64 slots, odd row stride)
             return (row & ~15) | ((row + (row >> 4)) & 15);
-        } else if constexpr (K >= 64 && !RowShape<K>::MIXED) {
+        } else if constexpr (K >= 64 && !RowShape<K>::MIXED && !RowShape<K>::WIDE3) {
             const int b = (row >> 4) & 3, c = (row >> 2) & 3, d = row & 3;
             return (row & ~63) | (16 * b + 4 * ((c + b) & 3) + ((d + b) & 3));
         } else {
@@ -178,6 +181,7 @@ template <int K> struct FftLayout {
 template <int K> struct FftTwiddles {
     cf w[RowShape<K>::WIDE ? 1 : RowShape<K>::NP4][3];
     cf w16[RowShape<K>::WIDE_R0 > 1 ? RowShape<K>::WIDE_R0 - 1 : 1];       // wide first pass of radix R0: W_K^{tq u}, u = 1 .. R0 - 1
+    cf wmid[RowShape<K>::WIDE3 ? RowShape<K>::WIDE_R1 - 1 : 1];            // three-pass plans, middle pass: W_K^{qq R0 u}, u = 1 .. R1 - 1
 };
 
 template <int K>
@@ -187,6 +191,10 @@ __device__ __forceinline__ void load_fft_twiddles(FftTwiddles<K>& t, int lane, c
     if constexpr (S::WIDE) {
         const int tq0 = lane % (K / S::WIDE_R0);
         static_for<1, S::WIDE_R0>([&](auto ui) { constexpr int u = decltype(ui)::value; t.w16[u - 1] = wK[wrap_k<K>(tq0 * u)]; });
+        if constexpr (S::WIDE3) {
+            const int qq = (lane % (K / S::WIDE_R1)) / S::WIDE_R0;
+            static_for<1, S::WIDE_R1>([&](auto ui) { constexpr int u = decltype(ui)::value; t.wmid[u - 1] = wK[wrap_k<K>(qq * S::WIDE_R0 * u)]; });
+        }
         return;
     }
     const int tq = lane % S::RG;
@@ -255,12 +263,90 @@ __device__ __forceinline__ void lds_subcarrier_fft2(cf* tile, int lane, const Ff
     }
 }
 
+// Three Stockham passes of radix R0, R1, R2 (R0 R1 R2 = K), in place: pass 0 and the last pass as in lds_subcarrier_fft2; the middle
+// pass (stride R0) reads rows tq + (K / R1) r and writes rows j + R0 (R1 qq + u), j = tq % R0, qq = tq / R0, with twiddle
+// W_K^{qq R0 u}.  K = 512 = 8 x 8 x 8 and K = 1024 = 8 x 8 x 16.
+template <int K, int M, bool INV, int R0, int R1, int R2>
+__device__ __forceinline__ void lds_subcarrier_fft3(cf* tile, int lane, const FftTwiddles<K>& twd)
+{
+    static_assert(R0 * R1 * R2 == K, "three-pass plan");
+    using LY = FftLayout<K>;
+    {
+        constexpr int RG = K / R0, CMAX = (M + R0 - 1) / R0;
+        const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+        cf x[CMAX][R0];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) static_for<0, R0>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
+        });
+        block_sync<K>();
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                Dft<R0, INV>::run(x[c]);
+                static_for<0, R0>([&](auto ui) {
+                    constexpr int u = decltype(ui)::value;
+                    cf y = x[c][u];
+                    if constexpr (u > 0) y = cmul_dir<INV>(y, twd.w16[u - 1]);
+                    tile[LY::slot(R0 * tq + u) * M + c0 + c] = y;
+                });
+            }
+        });
+        block_sync<K>();
+    }
+    {
+        constexpr int RG = K / R1, CMAX = (M + R1 - 1) / R1;
+        const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+        const int j = tq % R0, qq = tq / R0;
+        cf x[CMAX][R1];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) static_for<0, R1>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
+        });
+        block_sync<K>();
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                Dft<R1, INV>::run(x[c]);
+                static_for<0, R1>([&](auto ui) {
+                    constexpr int u = decltype(ui)::value;
+                    cf y = x[c][u];
+                    if constexpr (u > 0) y = cmul_dir<INV>(y, twd.wmid[u - 1]);
+                    tile[LY::slot(j + R0 * (R1 * qq + u)) * M + c0 + c] = y;
+                });
+            }
+        });
+        block_sync<K>();
+    }
+    {
+        constexpr int RG = K / R2, CMAX = (M + R2 - 1) / R2;
+        const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
+        cf x[CMAX][R2];
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) static_for<0, R2>([&](auto ri) { constexpr int r = decltype(ri)::value; x[c][r] = tile[LY::slot(tq + RG * r) * M + c0 + c]; });
+        });
+        block_sync<K>();
+        static_for<0, CMAX>([&](auto ci) {
+            constexpr int c = decltype(ci)::value;
+            if (c0 + c < M) {
+                Dft<R2, INV>::run(x[c]);
+                static_for<0, R2>([&](auto ui) { constexpr int u = decltype(ui)::value; tile[(tq + RG * u) * M + c0 + c] = x[c][u]; });      // natural order
+            }
+        });
+        block_sync<K>();
+    }
+}
+
 template <int K, int M, bool INV, int FIRST = 0>
 __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const FftTwiddles<K>& twd)
 {
     using S = RowShape<K>;
     using LY = FftLayout<K>;
-    if constexpr (S::WIDE) {
+    if constexpr (S::WIDE3) {
+        lds_subcarrier_fft3<K, M, INV, S::WIDE_R0, S::WIDE_R1, S::WIDE_R2>(tile, lane, twd);
+        return;
+    } else if constexpr (S::WIDE) {
         lds_subcarrier_fft2<K, M, INV, S::WIDE_R0, S::WIDE_R1>(tile, lane, twd);
         return;
     }

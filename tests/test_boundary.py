@@ -144,7 +144,7 @@ def test_row_lane_kernels_build_through_hiprtc(tmp_path, monkeypatch):
     assert L.gfdm_hip_jit_build_for_testing(3, 48, 4, 1) == 0, L.gfdm_hip_last_error()       # K = 48 = 3 x 16
     # K with a factor the two-pass plan cannot hold (34 = 2 x 17, 200 = 20 x 10, 320 > 256), M / K / L out of range
     assert L.gfdm_hip_jit_build_for_testing(7, 16, 2, 5) != 0                                # there is no part 5
-    for (M, K, Lp) in ((9, 34, 2), (9, 200, 2), (9, 320, 2), (127, 16, 2), (9, 1024, 2), (2, 16, 2), (9, 64, 1), (33, 64, 2), (9, 6, 8)):
+    for (M, K, Lp) in ((9, 34, 2), (9, 200, 2), (9, 320, 2), (127, 16, 2), (9, 2048, 2), (19, 1024, 2), (2, 16, 2), (9, 64, 1), (33, 64, 2), (9, 6, 8)):
         assert L.gfdm_hip_jit_build_for_testing(M, K, Lp, 0) != 0
 
 
