@@ -39,7 +39,15 @@ for shape in "128 15 4" "256 31 2"; do for b in 8192 65536; do
     rocprofv3 --kernel-trace --output-format csv -d $O/shape_trace/$tag/$p -o t -- python3 $R/scratch/run_kernel.py $p $b 40 2 $shape > /dev/null 2>&1
   done
 done; done
-for d in $O/shape_trace/*/*; do python3 $R/scratch/trace_by_shape.py $d/t_kernel_trace.csv | awk -v t=$(basename $(dirname $d)) -v p=$(basename $d) 'NR==1 && !h {print "shape_batch,path," $0; h=1} NR>1 {print t "," p "," $0}'; done | awk 'NR==1 || !/^shape_batch/' > $O/shape_kernel_durations.csv
+for d in $O/shape_trace/*/*; do python3 $R/scratch/trace_by_shape.py $d/t_kernel_trace.csv | awk -v t=$(basename $(dirname $d)) -v p=$(basename $d) 'NR==1 && !h {print "shape_batch,path," $0; h=1} NR>1 {print t "," p "," $0}'; done | awk 'NR==1 || !/^shape_batch/' > $O/shape_kernel_durations_all.csv
+python3 - "$O" <<PYEOF
+import csv, sys
+O = sys.argv[1]
+rows = list(csv.reader(open(O + "/shape_kernel_durations_all.csv")))
+keep = [r for r in rows[1:] if ("k_row_modulate" in r[2] if r[1] == "modulate" else "k_row_receive" in r[2])]
+w = csv.writer(open(O + "/shape_kernel_durations.csv", "w", newline=""))
+w.writerow(rows[0]); w.writerows(keep)
+PYEOF
 # 5. event-timed per-shape tables and the fused transmitter / frame receiver / estimator scripts
 python3 $R/scratch/bench_shape.py 64 9 2 65536 > $O/shape_64_9_2_65536.txt 2>&1
 python3 $R/scratch/bench_shape.py 32 5 2 65536 0.5 > $O/shape_32_5_2_65536.txt 2>&1
@@ -48,7 +56,10 @@ python3 $R/scratch/bench_shape.py 128 15 4 65536 > $O/shape_128_15_4_65536.txt 2
 python3 $R/scratch/bench_shape.py 256 31 2 8192 0.1 > $O/shape_256_31_2_8192.txt 2>&1
 python3 $R/scratch/bench_shape.py 128 21 2 4096 0.35 > $O/shape_128_21_2_4096.txt 2>&1
 python3 $R/scratch/bench_shape.py 16 7 2 65536 0.3 > $O/shape_16_7_2_65536_jit.txt 2>&1
-python3 $R/scratch/bench_shape.py 96 25 2 4096 0.35 > $O/shape_96_25_2_4096_generic.txt 2>&1
+python3 $R/scratch/bench_shape.py 96 25 2 4096 0.35 > $O/shape_96_25_2_4096.txt 2>&1
+python3 $R/scratch/bench_shape.py 16 127 2 4096 0.5 > $O/shape_16_127_2_4096_generic.txt 2>&1
+python3 $R/scratch/bench_shape.py 1024 15 2 2048 > $O/shape_1024_15_2_2048_jit.txt 2>&1
+python3 $R/scratch/bench_stages.py > $O/bench_stages.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/est -o est -- python3 $R/scratch/bench_est.py > $O/bench_est.txt 2>&1
 python3 $R/scratch/bench_tx.py > $O/bench_tx.txt 2>&1
 python3 $R/scratch/bench_frames.py > $O/bench_frames.txt 2>&1
