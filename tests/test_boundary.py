@@ -29,6 +29,34 @@ def test_library_exports_every_declared_symbol():
     assert set(gfdm_amd.exported_symbols()) == set(names), "ctypes binding and header disagree"
 
 
+def test_header_is_plain_c():
+    """the boundary is a C ABI: include/gfdm_hip.h must compile as C99 on its own (plain pointers and sizes, no C++ or torch types)"""
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", HEADER])
+
+
+@pytest.mark.gpu
+def test_c_program_runs_a_block_on_the_gpu(tmp_path):
+    """the same C program where a GPU is present: error codes and a block through the modulator and the receiver"""
+    if not have_gpu():
+        pytest.fail("no MI355X visible")
+    test_c_program_links_and_calls_the_boundary(tmp_path)
+
+
+def test_c_program_links_and_calls_the_boundary(tmp_path):
+    """tests/c_abi_smoke.c, compiled as C99 against include/gfdm_hip.h and linked with libgfdm_hip.so only: runs here (no GPU: every
+    create must answer GFDM_HIP_ENODEV) and on the GPU box (a block through the modulator and the receiver)."""
+    import subprocess
+    import gfdm_amd
+    libdir = os.path.dirname(gfdm_amd.capi.LIB_PATH)
+    exe = str(tmp_path / "c_abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi_smoke.c"),
+                           "-L" + libdir, "-lgfdm_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert ("no device" in out.stdout) != have_gpu()
+
+
 def test_strerror_and_version():
     import gfdm_amd
     L = gfdm_amd.lib()
