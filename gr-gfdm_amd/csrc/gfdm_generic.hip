@@ -67,24 +67,41 @@ __device__ __forceinline__ DevicePlan stage_tables(const DevicePlan& p, unsigned
     return q;                                   // the caller's first __syncthreads() publishes the tables
 }
 
-// dst[r*M + m] = scale * sum_p src[r*rs + p*ps] * W_M^{+-(p m)}      (dst may be LDS or global)
+// One pass over v_p and the roots w_p = W_M^{p m} yields TWO outputs of the direct DFT, m and M - m: W_M^{p (M - m)} = conj(w_p), so with
+// v = a + j b, w = c + j s the sums P1 = sum a c, P2 = sum b s, P3 = sum a s, P4 = sum b c give  sum v w = (P1 - P2, P3 + P4)  and
+// sum v conj(w) = (P1 + P2, P4 - P3): four multiply-adds and two LDS reads per term for the pair instead of eight and four.
+struct DftPair {
+    float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+    __device__ __forceinline__ void add(cf v, cf w)
+    {
+        p1 = fmaf(v.x, w.x, p1);
+        p2 = fmaf(v.y, w.y, p2);
+        p3 = fmaf(v.x, w.y, p3);
+        p4 = fmaf(v.y, w.x, p4);
+    }
+    __device__ __forceinline__ cf with_root() const { return make_float2(p1 - p2, p3 + p4); }        // sum v w
+    __device__ __forceinline__ cf with_conj() const { return make_float2(p1 + p2, p4 - p3); }        // sum v conj(w)
+};
+
+// dst[r*M + m] = scale * sum_p src[r*rs + p*ps] * W_M^{+-(p m)}      (dst may be LDS or global); one work item per pair (m, M - m)
 template <bool INV>
 __device__ void row_dft(cf* dst, const cf* src, int rows, int M, int rs, int ps, const cf* __restrict__ wM, float scale)
 {
-    DivStep ix(threadIdx.x, GT, M);
-    for (int idx = threadIdx.x; idx < rows * M; idx += GT, ix.next()) {
-        const int r = ix.q, m = ix.r;
-        cf acc = make_float2(0.f, 0.f);
+    const int H = M / 2 + 1;
+    DivStep ix(threadIdx.x, GT, H);
+    for (int idx = threadIdx.x; idx < rows * H; idx += GT, ix.next()) {
+        const int r = ix.q, m = ix.r, m2 = (m == 0) ? 0 : M - m;
+        DftPair acc;
         int e = 0;
         const cf* row = src + r * rs;
         for (int p = 0; p < M; ++p) {
-            const cf w = wM[e];
-            const cf v = row[p * ps];
-            acc = INV ? cfmaj(v, w, acc) : cfma(v, w, acc);
+            acc.add(row[p * ps], wM[e]);
             e += m;
             if (e >= M) e -= M;
         }
-        dst[idx] = make_float2(acc.x * scale, acc.y * scale);
+        const cf ya = INV ? acc.with_conj() : acc.with_root(), yb = INV ? acc.with_root() : acc.with_conj();
+        dst[r * M + m] = make_float2(ya.x * scale, ya.y * scale);
+        if (m2 != m) dst[r * M + m2] = make_float2(yb.x * scale, yb.y * scale);
     }
 }
 
@@ -200,19 +217,21 @@ __device__ __forceinline__ cf decide(cf x, const IcParams& ic)
 __device__ void cancel_rows(cf* dst, const cf* td, const cf* fd, const DevicePlan& p)
 {
     const int M = p.M, K = p.K;
-    DivStep ix(threadIdx.x, GT, M);
-    for (int idx = threadIdx.x; idx < p.N; idx += GT, ix.next()) {
-        const int k = ix.q, m = ix.r;
+    const int H = M / 2 + 1;
+    DivStep ix(threadIdx.x, GT, H);
+    for (int idx = threadIdx.x; idx < K * H; idx += GT, ix.next()) {
+        const int k = ix.q, m = ix.r, m2 = (m == 0) ? 0 : M - m;
         const cf* prev = td + (k == 0 ? K - 1 : k - 1) * M;
         const cf* next = td + (k == K - 1 ? 0 : k + 1) * M;
-        cf acc = make_float2(0.f, 0.f);
+        DftPair acc;
         int e = 0;
         for (int q = 0; q < M; ++q) {
-            acc = cfma(cadd(prev[q], next[q]), p.wM[e], acc);
+            acc.add(cadd(prev[q], next[q]), p.wM[e]);
             e += m;
             if (e >= M) e -= M;
         }
-        dst[idx] = csub(fd[idx], cmul(p.ictaps[m], acc));
+        dst[k * M + m] = csub(fd[k * M + m], cmul(p.ictaps[m], acc.with_root()));
+        if (m2 != m) dst[k * M + m2] = csub(fd[k * M + m2], cmul(p.ictaps[m2], acc.with_conj()));
     }
 }
 
@@ -285,18 +304,24 @@ __global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan pg, TxParams
     // x[K p + q] = (1/N) sum_m u[q][m] conj(W_M^{p m});  q fastest so the global store is coalesced   :137-140
     const float scale = 1.f / (float)N;
     DivStep px(threadIdx.x, GT, K);
-    for (int idx = threadIdx.x; idx < N; idx += GT, px.next()) {
-        const int pp = px.q, q = px.r;
-        cf acc = make_float2(0.f, 0.f);
+    for (int idx = threadIdx.x; idx < K * (M / 2 + 1); idx += GT, px.next()) {       // time slots pp and M - pp from one pass (DftPair)
+        const int pp = px.q, q = px.r, pp2 = (pp == 0) ? 0 : M - pp;
+        DftPair acc;
         int e = 0;
         for (int m = 0; m < M; ++m) {
-            acc = cfmaj(u[q * M + m], p.wM[e], acc);
+            acc.add(u[q * M + m], p.wM[e]);
             e += pp;
             if (e >= M) e -= M;
         }
-        const cf y = make_float2(acc.x * scale, acc.y * scale);
-        if (tx.framed) tx_store_sample(tx, blk, N, idx, y);             // cyclic prefix / suffix + ramp, every port
-        else o[idx] = y;
+        const cf ya = acc.with_conj(), yb = acc.with_root();           // inverse transform: conj(W_M^{p m}) for pp, the root itself for M - pp
+        const cf y = make_float2(ya.x * scale, ya.y * scale);
+        if (tx.framed) tx_store_sample(tx, blk, N, K * pp + q, y);      // cyclic prefix / suffix + ramp, every port
+        else o[K * pp + q] = y;
+        if (pp2 != pp) {
+            const cf y2 = make_float2(yb.x * scale, yb.y * scale);
+            if (tx.framed) tx_store_sample(tx, blk, N, K * pp2 + q, y2);
+            else o[K * pp2 + q] = y2;
+        }
     }
     if (tx.framed) tx_store_preamble(tx, blk, threadIdx.x, GT);
 }
@@ -339,17 +364,19 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams 
     for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
     __syncthreads();
     // A[q][m] = W_N^{q m} * sum_p x[K p + q] W_M^{p m}
-    DivStep ax(threadIdx.x, GT, M);
-    for (int idx = threadIdx.x; idx < N; idx += GT, ax.next()) {
-        const int q = ax.q, m = ax.r;
-        cf acc = make_float2(0.f, 0.f);
+    const int MH = M / 2 + 1;                                      // outputs m and M - m from one pass (DftPair)
+    DivStep ax(threadIdx.x, GT, MH);
+    for (int idx = threadIdx.x; idx < K * MH; idx += GT, ax.next()) {
+        const int q = ax.q, m = ax.r, m2 = (m == 0) ? 0 : M - m;
+        DftPair acc;
         int e = 0;
         for (int pp = 0; pp < M; ++pp) {
-            acc = cfma(t1[K * pp + q], p.wM[e], acc);
+            acc.add(t1[K * pp + q], p.wM[e]);
             e += m;
             if (e >= M) e -= M;
         }
-        t0[idx] = cmul(acc, p.wN[q * m]);
+        t0[q * M + m] = cmul(acc.with_root(), p.wN[q * m]);
+        if (m2 != m) t0[q * M + m2] = cmul(acc.with_conj(), p.wN[q * m2]);
     }
     __syncthreads();
     cf* X = col_fft<false>(t0, t1, p);                             // X[j][m] = FFT_N(x)[M j + m]       :304-305
