@@ -683,3 +683,25 @@ def test_blocks_larger_than_the_lds(M, K, L):
     for b in (3, nb // 2 // 3 * 3, (nb - 3) // 3 * 3):
         assert torch.equal(out[b:b + 3], first)
     assert rel_err(first.cpu().numpy()[keep], ref[keep]) < TOL
+
+
+def test_damaged_cache_entry_is_recompiled(tmp_path, monkeypatch):
+    """a truncated code object in the disk cache of the run-time instantiated kernels must not strand the shape on the generic family:
+    the part is compiled afresh and the cache entry replaced"""
+    import gfdm_amd
+    monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(tmp_path))
+    M, K, L = 3, 40, 2                                           # a shape no other test loads in this process
+    L_ = gfdm_amd.lib()
+    assert L_.gfdm_hip_jit_build_for_testing(M, K, L, 3) == 0    # fills the cache without loading the module
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(files) == 1
+    path = os.path.join(tmp_path, files[0])
+    good = os.path.getsize(path)
+    with open(path, "r+b") as f:
+        f.truncate(good // 3)
+    taps = get_frequency_domain_filter("rrc", 0.3, M, K, L)
+    mod = gfdm_amd.Modulator(M, K, L, taps)
+    assert mod.kernel_name() == "rowlane_jit" and os.path.getsize(path) == good
+    rng = np.random.default_rng(0)
+    d = qpsk(rng, (4, M * K))
+    assert rel_err(mod.modulate(d), R.modulate(d, R.normalize_taps(taps, M), M, K, L)) < TOL
