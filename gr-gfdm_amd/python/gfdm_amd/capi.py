@@ -664,7 +664,7 @@ class ResourceMapper(_Kernel):
         a = _c64(x)
         out = np.empty((nb, n_out), np.complex64)
         _check(host(self._h, out.ctypes.data, a.ctypes.data, size_arg, nb))
-        return out[0] if np.asarray(x).ndim == 1 else out
+        return out[0] if (np.asarray(x).ndim == 1 and nb == 1) else out
 
     def map_to_resources(self, symbols, ninput_size=None, stream=None, out=None):
         """ninput_size symbols per block (default block_size) -> frame_size grid values per block, unfilled slots zero."""
@@ -722,7 +722,7 @@ class CyclicPrefixer(_Kernel):
         a = _c64(blocks)
         out = np.empty((nb, F), np.complex64)
         _check(L.gfdm_hip_cyclic_prefixer_add_host(self._h, out.ctypes.data, a.ctypes.data, s, nb))
-        return out[0] if np.asarray(blocks).ndim == 1 else out
+        return out[0] if (np.asarray(blocks).ndim == 1 and nb == 1) else out
 
     generic_work = add_cyclic_prefix
 
@@ -739,7 +739,7 @@ class CyclicPrefixer(_Kernel):
         a = _c64(frames)
         out = np.empty((nb, N), np.complex64)
         _check(L.gfdm_hip_cyclic_prefixer_remove_host(self._h, out.ctypes.data, a.ctypes.data, nb))
-        return out[0] if np.asarray(frames).ndim == 1 else out
+        return out[0] if (np.asarray(frames).ndim == 1 and nb == 1) else out
 
 
 class ChannelEstimator(_Kernel):

@@ -178,3 +178,47 @@ def test_stage_argument_errors():
         pc.remove_cyclic_prefix(np.zeros(9, np.complex64))
     with pytest.raises(ValueError, match="cyclic shift"):
         gfdm_amd.CyclicPrefixer(8, 4, 2, 0, np.zeros(0)).add_cyclic_prefix(np.zeros(8, np.complex64), cyclic_shift=3)
+
+
+@pytest.mark.parametrize("per_ts", [True, False])
+def test_reference_mapper_test_shape_through_the_block_body(per_ts):
+    """python/qa_resource_mapper_cc.py:38-88 / qa_resource_demapper_cc.py: 205 timeslots x 128 subcarriers, 110 active (centred map), three
+    frames through the block -- here through the batched general_work body and the scheduler stand-in, expectation from the oracle
+    (pinned to pygfdm's map_to_waveform_resources in tests/test_oracle.py)."""
+    import gfdm_python
+    T = gfdm_python._testing
+    M, K, A, frames = 205, 128, 110, 3
+    smap = np.arange(A) + (K - A) // 2
+    rng = np.random.default_rng(12)
+    sym = (((1 - 2 * rng.integers(0, 2, (frames, A * M))) + 1j * (1 - 2 * rng.integers(0, 2, (frames, A * M)))) / np.sqrt(2)).astype(np.complex64)
+    mapper = gfdm_python.Resource_mapper(M, K, A, smap.tolist(), per_ts)
+    grid, produced = T.scheduler_run_mapper(mapper, True, sym.reshape(-1), [(2 * K * M + 5, 3 * A * M), (4 * K * M, A * M)])
+    assert produced == [2, 1]
+    assert np.array_equal(grid, R.map_to_resources(sym, M, K, smap, per_ts).astype(np.complex64))
+    demapper = gfdm_python.Resource_mapper(M, K, A, smap.tolist(), per_ts, False)
+    back, produced = T.scheduler_run_mapper(demapper, False, grid.reshape(-1), [(3 * A * M, 3 * K * M)])
+    assert produced == [3] and np.array_equal(back, sym)
+
+
+def test_reference_prefixer_test_cases():
+    """python/qa_cyclic_prefixer_cc.py: :36-46 constructor accepts 2 * ramp_len or block_len + cp_len window taps and refuses
+    block_len; :48-62 plain cyclic prefix under an all-ones window; :64-94 cyclic prefix + suffix pinched by a raised-cosine ramp
+    (window built as pygfdm.cyclic_prefix.get_raised_cosine_ramp does: half-cosine flanks of ramp_len samples around ones)."""
+    import gfdm_amd
+    gfdm_amd.CyclicPrefixer(16 * 8, 4, 0, 4, np.arange(4 * 2))
+    gfdm_amd.CyclicPrefixer(16 * 8, 4, 0, 4, np.arange(16 * 8 + 4))
+    with pytest.raises(ValueError, match="number of window taps"):
+        gfdm_amd.CyclicPrefixer(16 * 8, 4, 0, 4, np.arange(16 * 8))
+    block_len, cp = 48, 8
+    data = (np.arange(block_len) + 1).astype(np.complex64)
+    got = gfdm_amd.CyclicPrefixer(block_len, cp, 0, 0, np.ones(block_len + cp)).add_cyclic_prefix(data)
+    assert np.array_equal(got, np.concatenate((data[-cp:], data)))
+    K, M, cp, ramp = 8, 8, 8, 4
+    cs, N = 2 * ramp, 64
+    F = N + cp + cs
+    flank = 0.5 * (1.0 + np.cos(np.pi * (np.arange(ramp) + 0.5) / ramp + np.pi))          # rising half cosine, 0 .. 1 exclusive
+    window = np.concatenate((flank, np.ones(F - 2 * ramp), flank[::-1]))
+    data = (np.arange(N) + 1).astype(np.complex64)
+    ref = np.concatenate((data[-cp:], data, data[:cs])) * window
+    got = gfdm_amd.CyclicPrefixer(N, cp, cs, ramp, window).add_cyclic_prefix(np.tile(data, 3))
+    assert got.shape == (3, F) and rel_err(got, np.tile(ref, (3, 1))) < 1e-6
