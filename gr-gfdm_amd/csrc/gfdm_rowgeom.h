@@ -12,8 +12,8 @@
 namespace gfdm {
 namespace rowgeom {
 
-// Subcarrier counts the family covers: powers of two 4 .. 1024 (radix-4 / wide passes, gfdm_rowlane_impl.h) and any other
-// K = R0 * R1 <= 256 with both factors <= 16 (two Stockham passes with the codelets Dft<R0>, Dft<R1>; R0 = 1: a single pass).
+// Subcarrier counts the family covers: powers of two 4 .. 1024 (radix-4 / wide passes, gfdm_rowlane_impl.h), any other
+// K = R0 * R1 <= 256 with both factors <= 16 (two Stockham passes with the codelets Dft<R0>, Dft<R1>; R0 = 1: a single pass) ...
 constexpr bool pow2(int K) { return K > 0 && (K & (K - 1)) == 0; }
 constexpr int mixed_r1(int K)                                                // radix of the LAST pass: the largest divisor <= 16
 {
@@ -24,7 +24,16 @@ constexpr int mixed_r1(int K)                                                // 
 }
 constexpr int mixed_r0(int K) { return K / mixed_r1(K); }
 constexpr bool mixed(int K) { return !pow2(K) && K >= 3 && K <= 256 && mixed_r0(K) <= 16; }
-constexpr bool supported(int K) { return (pow2(K) && K >= 4 && K <= 1024) || mixed(K); }
+// ... and, where no two-factor plan exists, K = R0 * R1 * R2 <= 1024 with all three <= 16 (200 = 2 x 10 x 10, 320, 384 = 2 x 12 x 16, 600, 960,
+// 1000 ...): R2 = the largest divisor <= 16 of K, then the two-factor plan of K / R2.  Three passes (lds_subcarrier_fft3).
+constexpr bool mixed3(int K)
+{
+    return !pow2(K) && !mixed(K) && K >= 3 && K <= 1024 && mixed_r1(K) > 1 && mixed_r0(K / mixed_r1(K)) <= 16 && mixed_r1(K / mixed_r1(K)) > 1;
+}
+constexpr int mixed3_r2(int K) { return mixed_r1(K); }
+constexpr int mixed3_r1(int K) { return mixed_r1(K / mixed_r1(K)); }
+constexpr int mixed3_r0(int K) { return K / mixed_r1(K) / mixed3_r1(K); }
+constexpr bool supported(int K) { return (pow2(K) && K >= 4 && K <= 1024) || mixed(K) || mixed3(K); }
 
 // threads per workgroup: whole blocks only (a block never straddles two workgroups)
 constexpr int wg(int K) { return K >= 128 ? K : pow2(K) ? GFDM_ROW_WG : (GFDM_ROW_WG / K) * K; }

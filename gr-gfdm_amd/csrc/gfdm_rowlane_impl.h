@@ -72,7 +72,8 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #endif
 
 template <int K> struct RowShape {
-    static_assert(rowgeom::supported(K), "row-lane family: K a power of two 4 .. 1024, or K = R0 * R1 <= 256 with both factors <= 16");
+    static_assert(rowgeom::supported(K), "row-lane family: K a power of two 4 .. 1024, K = R0 * R1 <= 256 or K = R0 * R1 * R2 <= 1024 with all factors <= 16");
+    static constexpr bool MIXED3 = rowgeom::mixed3(K);     // no two-factor plan: three passes
     // K not a power of two: two Stockham passes of radix R0 and R1 (R0 = 1: one pass), lds_subcarrier_fft2
     static constexpr bool MIXED = rowgeom::mixed(K);
     static constexpr int R0 = MIXED ? rowgeom::mixed_r0(K) : 1, R1 = MIXED ? rowgeom::mixed_r1(K) : 1;
@@ -97,11 +98,12 @@ template <int K> struct RowShape {
     static constexpr bool RADIX8X16 = false;
 #endif
     // K = 512 = 8 x 8 x 8, K = 1024 = 8 x 8 x 16: THREE wide passes (lds_subcarrier_fft3) instead of four or five radix-4 / radix-2 passes
-    static constexpr bool WIDE3 = (K == 512 || K == 1024);
+    static constexpr bool WIDE3 = (K == 512 || K == 1024) || MIXED3;
     static constexpr bool WIDE = RADIX16 || RADIX8X16 || MIXED || WIDE3;   // FftTwiddles holds the twiddles of the wide passes
-    static constexpr int WIDE_R0 = (RADIX16 ? 16 : RADIX8X16 ? 8 : MIXED ? R0 : WIDE3 ? 8 : 1);
-    static constexpr int WIDE_R1 = (RADIX16 || RADIX8X16) ? 16 : MIXED ? R1 : WIDE3 ? 8 : 1;
-    static constexpr int WIDE_R2 = WIDE3 ? K / 64 : 1;
+    static constexpr int WIDE_R0 = (RADIX16 ? 16 : RADIX8X16 ? 8 : MIXED ? R0 : MIXED3 ? rowgeom::mixed3_r0(K) : WIDE3 ? 8 : 1);
+    static constexpr int WIDE_R1 = (RADIX16 || RADIX8X16) ? 16 : MIXED ? R1 : MIXED3 ? rowgeom::mixed3_r1(K) : WIDE3 ? 8 : 1;
+    static constexpr int WIDE_R2 = MIXED3 ? rowgeom::mixed3_r2(K) : WIDE3 ? K / 64 : 1;
+    static constexpr bool LDS_REDUCE = MIXED || MIXED3;    // lanes of a block not aligned to wavefronts: block-wide sums go through the tile
 };
 
 // x mod K for 0 <= x (row and twiddle indices): a mask where K is a power of two, a constant division otherwise
@@ -162,7 +164,7 @@ template <int K> struct FftLayout {
             // radix-16 passes: 16 neighbouring lanes touch rows tq + 16 r (reads, phase A), 16 tq + u (pass-0 writes); rotating the
             // low four row bits by the next four keeps the slots of both patterns distinct mod 32 (b64 slots, odd row stride)
             return (row & ~15) | ((row + (row >> 4)) & 15);
-        } else if constexpr (K >= 64 && !RowShape<K>::MIXED && !RowShape<K>::WIDE3) {
+        } else if constexpr (K >= 64 && rowgeom::pow2(K) && !RowShape<K>::WIDE3) {
             const int b = (row >> 4) & 3, c = (row >> 2) & 3, d = row & 3;
             return (row & ~63) | (16 * b + 4 * ((c + b) & 3) + ((d + b) & 3));
         } else {
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
                 });
             }
             if (pc) {                                                                                    // adv:59-71, 78-91
-                if constexpr (S::MIXED) {
+                if constexpr (S::LDS_REDUCE) {
                     // the block's lanes are not aligned to wavefronts: sum through the (free) tile
                     float* part = reinterpret_cast<float*>(X);
                     part[q] = acc;

@@ -526,11 +526,12 @@ def test_generic_family_any_subcarrier_count(M, K, L):
 
 @pytest.mark.parametrize("M,K,L,alpha", [(7, 16, 2, 0.3), (13, 32, 4, 0.4), (11, 8, 2, 0.5), (27, 128, 2, 0.2), (6, 256, 2, 0.3), (28, 64, 2, 0.1), (5, 4, 8, 0.5),
                                          (10, 96, 2, 0.35), (21, 12, 2, 0.35), (9, 48, 4, 0.3), (7, 240, 2, 0.2), (15, 80, 2, 0.3), (9, 15, 2, 0.4), (3, 6, 2, 0.5),
-                                         (4, 100, 2, 0.5), (5, 20, 6, 0.4), (9, 512, 2, 0.3), (15, 1024, 2, 0.2)])
+                                         (4, 100, 2, 0.5), (5, 20, 6, 0.4), (9, 512, 2, 0.3), (15, 1024, 2, 0.2),
+                                         (9, 384, 2, 0.3), (5, 600, 2, 0.2), (9, 200, 2, 0.4)])
 def test_row_lane_kernels_instantiated_at_run_time(M, K, L, alpha, tmp_path, monkeypatch):
     """Shapes outside the compiled list get the row-lane kernels instantiated through hiprtc when the handle is created
     (gfdm_jit.hip) -- K a power of two, or K = R0 x R1 with both factors <= 16 (96 = 6 x 16, 12, 48 = 3 x 16, 240 = 15 x 16, 80, 15,
-    6, 100 = 10 x 10, 20; 512 and 1024 take three wide passes): every mode against the oracle, and the switch that turns the run-time instantiation off."""
+    6, 100 = 10 x 10, 20; 512, 1024 and the K without a two-factor plan -- 384, 600, 200 -- take three wide passes): every mode against the oracle, and the switch that turns the run-time instantiation off."""
     import gfdm_amd
     monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(tmp_path))       # cold cache: really compile
     rng = np.random.default_rng(31 * M + K + L)
