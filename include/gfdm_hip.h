@@ -67,7 +67,7 @@ int gfdm_hip_device_count(void);
 int gfdm_hip_force_generic_family_for_testing(int enable);
 /* Run-time instantiation of the tuned (row-lane) kernels for shapes outside the library's compiled list: a handle for a shape with
  * a power-of-two number of subcarriers (4 .. 1024) or one that is a product of two factors <= 16 (12, 20, 48, 96, 100, 240 ...; at most 256) or of three (200, 384, 600, 1000 ...; at most 1024),
- * 3 .. 32 timeslots and overlap 2 .. 8 -- as far as the block fits the CU's 160 KB LDS (every shape up to 512 subcarriers does; 1024 x 17) -- gets the kernels compiled for exactly that
+ * 3 .. 48 timeslots and overlap 2 .. 8 -- as far as the block fits the CU's 160 KB LDS (every shape up to 512 subcarriers does; 1024 x 17) -- gets the kernels compiled for exactly that
  * shape through hiprtc when it is created (1-10 s per part; a handle compiles only the parts of its kind -- a modulator the
  * modulator kernels, a receiver the receive kernels, ... -- the rest at first use; the code objects are cached under $GFDM_HIP_CACHE_DIR,
  * else $XDG_CACHE_HOME/gfdm_hip, else ~/.cache/gfdm_hip, so this happens once per shape and machine) and reports kernel_name
