@@ -12,27 +12,36 @@
 namespace gfdm {
 namespace rowgeom {
 
-// Subcarrier counts the family covers: powers of two 4 .. 1024 (radix-4 / wide passes, gfdm_rowlane_impl.h), any other
-// K = R0 * R1 <= 256 with both factors <= 16 (two Stockham passes with the codelets Dft<R0>, Dft<R1>; R0 = 1: a single pass) ...
+// Subcarrier counts the family covers: powers of two 4 .. 1024 (radix-4 / wide passes, gfdm_rowlane_impl.h), and every other K <= 1024
+// that splits into two or three factors the butterfly codelets hold in registers -- Dft<R> for R <= 16 where such a plan exists
+// (96 = 6 x 16, 12, 48, 240; 200 = 2 x 10 x 10, 384, 600, 1000), else R <= 32 (34 = 2 x 17, 62 = 2 x 31, 51, 93, 589 = 19 x 31, a prime
+// K <= 31 itself).  Two passes are preferred to three; two-pass plans with factors <= 16 stay below K = 256.
+//   the LAST pass takes the largest divisor <= lim, the pass(es) in front the same rule on the quotient; R0 = 1: a single pass
 constexpr bool pow2(int K) { return K > 0 && (K & (K - 1)) == 0; }
-constexpr int mixed_r1(int K)                                                // radix of the LAST pass: the largest divisor <= 16
+constexpr int ldiv(int K, int lim)                                           // the largest divisor of K that is <= lim
 {
     int r = 1;
-    for (int d = 2; d <= 16 && d <= K; ++d)
+    for (int d = 2; d <= lim && d <= K; ++d)
         if (K % d == 0) r = d;
     return r;
 }
-constexpr int mixed_r0(int K) { return K / mixed_r1(K); }
-constexpr bool mixed(int K) { return !pow2(K) && K >= 3 && K <= 256 && mixed_r0(K) <= 16; }
-// ... and, where no two-factor plan exists, K = R0 * R1 * R2 <= 1024 with all three <= 16 (200 = 2 x 10 x 10, 320, 384 = 2 x 12 x 16, 600, 960,
-// 1000 ...): R2 = the largest divisor <= 16 of K, then the two-factor plan of K / R2.  Three passes (lds_subcarrier_fft3).
-constexpr bool mixed3(int K)
+constexpr bool plan2(int K, int lim) { return K / ldiv(K, lim) <= lim; }
+constexpr bool plan3(int K, int lim) { return ldiv(K, lim) > 1 && ldiv(K / ldiv(K, lim), lim) > 1 && plan2(K / ldiv(K, lim), lim); }
+// radix limit of K's plan: 16 if a two- or three-pass plan with factors <= 16 exists, else 32
+constexpr int plan_lim(int K) { return ((K <= 256 && plan2(K, 16)) || plan3(K, 16)) ? 16 : 32; }
+constexpr bool mixed(int K)                                                   // two passes
 {
-    return !pow2(K) && !mixed(K) && K >= 3 && K <= 1024 && mixed_r1(K) > 1 && mixed_r0(K / mixed_r1(K)) <= 16 && mixed_r1(K / mixed_r1(K)) > 1;
+    return !pow2(K) && K >= 3 && K <= 1024 && ((K <= 256 && plan2(K, 16)) || (!plan3(K, 16) && plan2(K, 32)));
 }
-constexpr int mixed3_r2(int K) { return mixed_r1(K); }
-constexpr int mixed3_r1(int K) { return mixed_r1(K / mixed_r1(K)); }
-constexpr int mixed3_r0(int K) { return K / mixed_r1(K) / mixed3_r1(K); }
+constexpr int mixed_r1(int K) { return ldiv(K, plan_lim(K)); }
+constexpr int mixed_r0(int K) { return K / mixed_r1(K); }
+constexpr bool mixed3(int K)                                                  // three passes
+{
+    return !pow2(K) && !mixed(K) && K >= 3 && K <= 1024 && (plan3(K, 16) || plan3(K, 32));
+}
+constexpr int mixed3_r2(int K) { return ldiv(K, plan_lim(K)); }
+constexpr int mixed3_r1(int K) { return ldiv(K / mixed3_r2(K), plan_lim(K)); }
+constexpr int mixed3_r0(int K) { return K / mixed3_r2(K) / mixed3_r1(K); }
 constexpr bool supported(int K) { return (pow2(K) && K >= 4 && K <= 1024) || mixed(K) || mixed3(K); }
 
 // threads per workgroup: whole blocks only (a block never straddles two workgroups)

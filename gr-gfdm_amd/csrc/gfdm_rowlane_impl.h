@@ -72,7 +72,7 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #endif
 
 template <int K> struct RowShape {
-    static_assert(rowgeom::supported(K), "row-lane family: K a power of two 4 .. 1024, K = R0 * R1 <= 256 or K = R0 * R1 * R2 <= 1024 with all factors <= 16");
+    static_assert(rowgeom::supported(K), "row-lane family: K a power of two 4 .. 1024, or K <= 1024 a product of two or three factors <= 32 (gfdm_rowgeom.h)");
     static constexpr bool MIXED3 = rowgeom::mixed3(K);     // no two-factor plan: three passes
     // K not a power of two: two Stockham passes of radix R0 and R1 (R0 = 1: one pass), lds_subcarrier_fft2
     static constexpr bool MIXED = rowgeom::mixed(K);

@@ -66,7 +66,7 @@ int gfdm_hip_device_count(void);
  * setting.  Nothing else (no environment variable) changes the kernel family of a handle. */
 int gfdm_hip_force_generic_family_for_testing(int enable);
 /* Run-time instantiation of the tuned (row-lane) kernels for shapes outside the library's compiled list: a handle for a shape with
- * a power-of-two number of subcarriers (4 .. 1024) or one that is a product of two factors <= 16 (12, 20, 48, 96, 100, 240 ...; at most 256) or of three (200, 384, 600, 1000 ...; at most 1024),
+ * a power-of-two number of subcarriers (4 .. 1024) or one up to 1024 that is a product of two or three factors <= 32 (12, 20, 34, 48, 96, 100, 240, 384, 600, 1000 ...),
  * 3 .. 48 timeslots and overlap 2 .. 8 -- as far as the block fits the CU's 160 KB LDS (every shape up to 512 subcarriers does; 1024 x 17) -- gets the kernels compiled for exactly that
  * shape through hiprtc when it is created (1-10 s per part; a handle compiles only the parts of its kind -- a modulator the
  * modulator kernels, a receiver the receive kernels, ... -- the rest at first use; the code objects are cached under $GFDM_HIP_CACHE_DIR,

@@ -170,10 +170,10 @@ def test_row_lane_kernels_build_through_hiprtc(tmp_path, monkeypatch):
     assert L.gfdm_hip_jit_build_for_testing(13, 32, 4, 1) == 0, L.gfdm_hip_last_error()      # overlap 4, IC kernels
     assert L.gfdm_hip_jit_build_for_testing(5, 12, 2, 0) == 0, L.gfdm_hip_last_error()       # K = 12: not a power of two, one radix-12 pass
     assert L.gfdm_hip_jit_build_for_testing(3, 48, 4, 1) == 0, L.gfdm_hip_last_error()       # K = 48 = 3 x 16
-    # K with a prime factor above 16 (34 = 2 x 17, 1023 = 3 x 11 x 31) or above 1024, M / K / L out of range
+    # K with a prime factor above 32 (74 = 2 x 37, the prime 1021) or above 1024, M / K / L out of range
     assert L.gfdm_hip_jit_build_for_testing(7, 16, 2, 5) != 0                                # there is no part 5
     assert L.gfdm_hip_jit_build_for_testing(3, 200, 2, 0) == 0, L.gfdm_hip_last_error()      # K = 200 = 2 x 10 x 10: three passes
-    for (M, K, Lp) in ((9, 34, 2), (9, 1023, 2), (9, 1040, 2), (127, 16, 2), (9, 2048, 2), (19, 1024, 2), (2, 16, 2), (9, 64, 1), (49, 64, 2), (9, 6, 8)):
+    for (M, K, Lp) in ((9, 74, 2), (9, 1021, 2), (9, 1040, 2), (127, 16, 2), (9, 2048, 2), (19, 1024, 2), (2, 16, 2), (9, 64, 1), (49, 64, 2), (9, 6, 8)):
         assert L.gfdm_hip_jit_build_for_testing(M, K, Lp, 0) != 0
 
 

@@ -392,8 +392,8 @@ def test_baseline_shapes_run_on_the_tuned_family():
         assert gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points()).kernel_name() == "rowlane"
     taps = get_frequency_domain_filter("rrc", 0.35, 127, 16, 2)                  # M > 48: no register codelet
     assert gfdm_amd.Demodulator(127, 16, 2, taps).kernel_name() == "generic_lds"
-    taps = get_frequency_domain_filter("rrc", 0.35, 9, 34, 2)                    # K = 2 x 17: no two-pass plan
-    assert gfdm_amd.Demodulator(9, 34, 2, taps).kernel_name() == "generic_lds"
+    taps = get_frequency_domain_filter("rrc", 0.35, 9, 74, 2)                    # K = 2 x 37: a prime factor above 32, no butterfly codelet
+    assert gfdm_amd.Demodulator(9, 74, 2, taps).kernel_name() == "generic_lds"
 
 
 @pytest.mark.parametrize("M,K,L,alpha", SHAPES[:4])
@@ -527,11 +527,13 @@ def test_generic_family_any_subcarrier_count(M, K, L):
 @pytest.mark.parametrize("M,K,L,alpha", [(7, 16, 2, 0.3), (13, 32, 4, 0.4), (11, 8, 2, 0.5), (27, 128, 2, 0.2), (6, 256, 2, 0.3), (28, 64, 2, 0.1), (5, 4, 8, 0.5),
                                          (10, 96, 2, 0.35), (21, 12, 2, 0.35), (9, 48, 4, 0.3), (7, 240, 2, 0.2), (15, 80, 2, 0.3), (9, 15, 2, 0.4), (3, 6, 2, 0.5),
                                          (4, 100, 2, 0.5), (5, 20, 6, 0.4), (9, 512, 2, 0.3), (15, 1024, 2, 0.2),
-                                         (9, 384, 2, 0.3), (5, 600, 2, 0.2), (9, 200, 2, 0.4), (37, 32, 2, 0.3)])
+                                         (9, 384, 2, 0.3), (5, 600, 2, 0.2), (9, 200, 2, 0.4), (37, 32, 2, 0.3),
+                                         (9, 34, 2, 0.3), (5, 93, 2, 0.4), (3, 589, 2, 0.2), (9, 31, 2, 0.3)])
 def test_row_lane_kernels_instantiated_at_run_time(M, K, L, alpha, tmp_path, monkeypatch):
     """Shapes outside the compiled list get the row-lane kernels instantiated through hiprtc when the handle is created
     (gfdm_jit.hip) -- K a power of two, or K = R0 x R1 with both factors <= 16 (96 = 6 x 16, 12, 48 = 3 x 16, 240 = 15 x 16, 80, 15,
-    6, 100 = 10 x 10, 20; 512, 1024 and the K without a two-factor plan -- 384, 600, 200 -- take three wide passes): every mode against the oracle, and the switch that turns the run-time instantiation off."""
+    6, 100 = 10 x 10, 20; 512, 1024 and the K without a two-factor plan -- 384, 600, 200 -- take three wide passes; 34 = 2 x 17, 93 = 3 x 31,
+    589 = 19 x 31 and the prime 31 use butterflies of up to 32 points): every mode against the oracle, and the switch that turns the run-time instantiation off."""
     import gfdm_amd
     monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(tmp_path))       # cold cache: really compile
     rng = np.random.default_rng(31 * M + K + L)
