@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <memory>
 #include <string>
+#include <vector>
 
 namespace pmt {
 class pmt_base;
@@ -13,5 +14,9 @@ pmt_t intern(const std::string& s);
 pmt_t from_long(long x);
 pmt_t from_float(double x);
 pmt_t init_f32vector(size_t k, const float* data);
+pmt_t init_f32vector(size_t k, const std::vector<float>& data);
+long to_long(pmt_t x);
+bool eqv(const pmt_t& x, const pmt_t& y);
+const std::string symbol_to_string(const pmt_t& sym);
 } // namespace pmt
 #endif

@@ -149,6 +149,33 @@ def test_reference_pybind_bindings_compile_unchanged():
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only"] + inc + [os.path.join(ref, name)])
 
 
+def test_reference_gnuradio_wrappers_compile_unchanged_on_these_kernel_classes():
+    """north_star: "so the GNU Radio *_impl wrappers still drop in" (SURVEY.md section 8(f)4).  gr-gfdm's own block wrappers --
+    lib/{simple_modulator,simple_receiver,advanced_receiver_sb,transmitter,channel_estimator,resource_mapper,resource_demapper,
+    cyclic_prefixer}_cc_impl.cc, unmodified and from where they lie -- are syntax-checked with THIS repository's kernel class
+    headers in front of the reference's include directory (so <gfdm/modulator_kernel_cc.h> etc. are ours, and only the block-interface
+    headers such as <gfdm/simple_modulator_cc.h> come from the reference).  GNU Radio itself is absent: tests/mock_gnuradio declares
+    (declarations only, nothing links) the block-API names the wrappers use.  Any error naming a kernel-class member would be a
+    boundary bug.  Build-container only: the reference checkout does not exist on the GPU box."""
+    import subprocess
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "lib")):
+        pytest.skip("reference checkout not present")
+    ours = os.path.join(ROOT, "gr-gfdm_amd", "cpp", "include")
+    inc = ["-I" + ours, "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "mock_gnuradio"),
+           "-I" + os.path.join(ref, "include"), "-I" + os.path.join(ref, "lib")]
+    kernel_headers = {"simple_modulator": "modulator_kernel_cc.h", "simple_receiver": "receiver_kernel_cc.h",
+                      "advanced_receiver_sb": "advanced_receiver_kernel_cc.h", "transmitter": "transmitter_kernel.h",
+                      "channel_estimator": "preamble_channel_estimator_cc.h", "resource_mapper": "resource_mapper_kernel_cc.h",
+                      "resource_demapper": "resource_mapper_kernel_cc.h", "cyclic_prefixer": "add_cyclic_prefix_cc.h"}      # (remove_prefix_cc_impl.cc uses no kernel class)
+    for name, hdr in kernel_headers.items():
+        src = os.path.join(ref, "lib", name + "_cc_impl.cc")
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-H"] + inc + [src], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        used = [ln.split()[-1] for ln in r.stderr.splitlines() if ln.startswith(".") and ln.endswith("/gfdm/" + hdr)]
+        assert used and all(u.startswith(ours) for u in used), (name, used)      # the kernel class really is this repository's
+
+
 def test_row_lane_kernels_build_through_hiprtc(tmp_path, monkeypatch):
     """Run-time instantiation (gfdm_jit.hip): the kernel headers embedded in libgfdm_hip.so compile through hiprtc for shapes outside
     the compiled list (no GPU needed for the compile), the code object lands in the disk cache and is found there the second time;
