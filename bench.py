@@ -87,7 +87,7 @@ def parse(argv=None):
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained run of the headline loop (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the per-variant measurements")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall time of each cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="wall time of each cpu_baseline leg (two or three legs)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="no GPU, no GFDM compute: run launcher + rendezvous (gloo) + shard plan + synthetic-input checksum all-reduce "
                          "and print them (tests/test_bench_launcher.py)")
@@ -113,22 +113,23 @@ def free_port():
 def launch_ranks(a, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this host driver
-    env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(cmd, env=dict(os.environ))          # (main() has set the RCCL / OpenMP defaults already)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 
-def shard_plan(cfg, batch_override, rank, world):
-    """(blocks of this rank per step, first global block of this rank, total blocks per step, 'weak' | 'strong')"""
+def shard_plan(cfg, batch_override, rank, world, sharded=None):
+    """(blocks of this rank per step, first global block of this rank, total blocks per step, 'weak' | 'strong'); the split is the
+    product's own (gfdm_amd.sharding.ShardedBatch.shard, one device per process here)"""
     from gfdm_amd import sharding
+    shard = (lambda total: sharded.shard(total, 0)) if sharded is not None else (lambda total: sharding.shard_range(total, rank, world))
     if cfg["total"] is None:
         B = batch_override or cfg["batch"]
+        start, count = shard(B * world)
+        assert count == B and start == rank * B
         return B, None, B * world, "weak"
     total = batch_override or cfg["total"]
-    start, count = sharding.shard_range(total, rank, world)
+    start, count = shard(total)
     return count, start, total, "strong"
 
 
@@ -270,10 +271,47 @@ def allowed_cpus():
         return list(range(os.cpu_count() or 1))
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of run time this process may use per period, from the cgroup (v2 cpu.max, v1 cpu.cfs_quota_us / cfs_period_us), or
+    None when unlimited / not readable.  The affinity mask alone says nothing about it: a lease can see 256 CPUs and be granted 8."""
+    try:
+        rel = "/"
+        for line in open("/proc/self/cgroup"):
+            parts = line.strip().split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                rel = parts[2] or "/"
+        best = None
+        d = os.path.normpath("/sys/fs/cgroup" + rel)
+        while d.startswith("/sys/fs/cgroup"):                     # the tightest limit on the way up
+            try:
+                q, per = open(os.path.join(d, "cpu.max")).read().split()
+                if q != "max":
+                    v = float(q) / float(per)
+                    best = v if best is None else min(best, v)
+            except (OSError, ValueError):
+                pass
+            if d == "/sys/fs/cgroup":
+                break
+            d = os.path.dirname(d)
+        if best is not None:
+            return best
+    except OSError:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 and per > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, taps, seconds):
     """The plain-C oracle (reference algorithm, restated; FFTW/VOLK are not installed) on this config's step, driven by
     oracle/gfdm_oracle_bench.c: pinned pthreads, one kernel object each, block after block (how the reference's GNU Radio
-    wrappers drive its kernels) until a common deadline.  Leg 1: one thread.  Leg 2: one thread per CPU this process may run on."""
+    wrappers drive its kernels), timed from the moment every thread has finished its set-up.  Leg 1: one thread.  Leg 2: one thread
+    per CPU this process may run on, capped by the cgroup's CPU quota when one is set.  Where the host still delivers far less than
+    threads x single-thread rate (a lease limited by something this process cannot read), leg 3 runs as many threads as leg 2's
+    speed-up suggests; the faster of legs 2 / 3 is reported and `cores` is ITS thread count."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     try:    # rebuild for this host's ISA; fall back to the shipped portable build
@@ -285,24 +323,40 @@ def cpu_baseline(cfg, taps, seconds):
     K, M, L = cfg["K"], cfg["M"], cfg["L"]
     use_eq, ic_iter, _, cmode = MODES[cfg["mode"]]
     cpus = allowed_cpus()
+    quota = cgroup_cpu_quota()
     chunk = max(1, 16384 // (K * M) * 4)
-    n1, t1 = c_oracle.bench_threads(M, K, L, taps, cmode, 1, seconds, use_eq=use_eq, ic_iter=ic_iter, cpus=cpus, chunk=chunk, lib=lib)
-    T = len(cpus)
-    nT, tT = c_oracle.bench_threads(M, K, L, taps, cmode, T, seconds, use_eq=use_eq, ic_iter=ic_iter, cpus=cpus, chunk=chunk, lib=lib)
+    run = lambda T: c_oracle.bench_threads(M, K, L, taps, cmode, T, seconds, use_eq=use_eq, ic_iter=ic_iter, cpus=cpus, chunk=chunk, lib=lib)
+    n1, t1 = run(1)
+    single = n1 / t1
+    T_all = len(cpus) if quota is None else max(1, min(len(cpus), int(quota + 0.999)))
+    legs = []
+    nT, tT = run(T_all)
+    legs.append({"threads": T_all, "blocks": nT, "seconds": tT, "value": nT / tT})
+    speedup = legs[0]["value"] / single
+    if T_all > 2 and speedup < 0.5 * T_all:
+        T2 = max(2, min(T_all, int(round(speedup * 1.25))))
+        n2, t2 = run(T2)
+        legs.append({"threads": T2, "blocks": n2, "seconds": t2, "value": n2 / t2})
+    best = max(legs, key=lambda g: g["value"])
     model, phys = "", set()
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name") and not model:
                 model = line.split(":", 1)[1].strip()
-        for c in cpus:
+        for c in cpus[:best["threads"]]:
             phys.add(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip())
     except OSError:
         pass
-    return {"value": nT / tT, "unit": "blocks/s", "cores": T, "kind": "port",
+    return {"value": best["value"], "unit": "blocks/s", "cores": best["threads"], "kind": "port",
             "sample": "%s of QPSK blocks (K=%d M=%d L=%d) for %.1f s on %d pinned pthreads, one plain-C oracle kernel object per thread "
-                      "(-O3 -march=native, oracle/gfdm_oracle_bench.c): %d blocks; single thread: %d blocks in %.1f s"
-                      % (cfg["mode"], K, M, L, tT, T, nT, n1, t1),
-            "single_thread_value": n1 / t1, "single_thread_us_per_block": 1e6 * t1 / n1,
+                      "(-O3 -march=native, oracle/gfdm_oracle_bench.c; set-up not timed): %d blocks; single thread: %d blocks in %.1f s"
+                      % (cfg["mode"], K, M, L, best["seconds"], best["threads"], best["blocks"], n1, t1),
+            "single_thread_value": single, "single_thread_us_per_block": 1e6 * t1 / n1,
+            "scaling_vs_single_thread": best["value"] / single,
+            # what this process was really given: CPUs in the affinity mask, CPUs' worth of quota in the cgroup (None = no limit set),
+            # and the speed-up the threads delivered (effective cores = min of the three is what `cores` should be read against)
+            "cpus_in_affinity_mask": len(cpus), "cgroup_cpu_quota": quota, "effective_cores": min([len(cpus), best["value"] / single] + ([quota] if quota else [])),
+            "legs": legs,
             "cpu_model": model, "host_logical_cpus": os.cpu_count(), "physical_cores_used": len(phys) or None,
             # the reference's own CPU kernels need FFTW3f and VOLK; neither is installed on the boxes of this pool (probe),
             # so the only CPU figure is the plain-C restatement of the same per-block algorithm
@@ -329,6 +383,10 @@ def single_block_host(cfg, taps, reps=300):
 
 def main():
     argv = sys.argv[1:]
+    # before torch / RCCL are imported, and also when the ranks were started by somebody else's torchrun: dmabuf IPC (RCCL needs it on
+    # this host driver), one OpenMP thread per rank
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
     a = parse(argv)
     cfg = CONFIGS[a.config]
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -356,13 +414,16 @@ def main():
     K, M, L = cfg["K"], cfg["M"], cfg["L"]
     N = K * M
     use_eq, ic_iter, rx_bps, _ = MODES[cfg["mode"]]
-    plan = shard_plan(cfg, a.batch, rank, world)
-    B, _, total_per_step, scaling = plan
     taps = get_frequency_domain_filter("rrc", cfg["alpha"], M, K, L)
-    mod = gfdm_amd.Modulator(M, K, L, taps, device=local)
-    dem = gfdm_amd.Demodulator(M, K, L, np.conj(taps), device=local)          # rx taps = conj(tx taps)  (matched filter)
     qpsk = np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) / np.sqrt(2)
-    adv = gfdm_amd.AdvancedReceiver(M, K, L, np.conj(taps), np.arange(K), 2, qpsk, device=local)
+    # the batched-blocks multi-GPU mode of the product (gfdm_amd.sharding.ShardedBatch): one kernel handle per device of this process
+    # (one device per process under torchrun), contiguous shards, no data-path collective
+    sb_mod = sharding.ShardedBatch(lambda d: gfdm_amd.Modulator(M, K, L, taps, device=d), [local], rank, world)
+    sb_dem = sharding.ShardedBatch(lambda d: gfdm_amd.Demodulator(M, K, L, np.conj(taps), device=d), [local], rank, world)   # rx taps = conj(tx taps)
+    sb_adv = sharding.ShardedBatch(lambda d: gfdm_amd.AdvancedReceiver(M, K, L, np.conj(taps), np.arange(K), 2, qpsk, device=d), [local], rank, world)
+    mod, dem, adv = sb_mod.kernels[0], sb_dem.kernels[0], sb_adv.kernels[0]
+    plan = shard_plan(cfg, a.batch, rank, world, sb_dem)
+    B, _, total_per_step, scaling = plan
     L_ = gfdm_amd.lib()
     stream = torch.cuda.current_stream().cuda_stream
     buf_bytes = B * N * 8
@@ -390,8 +451,9 @@ def main():
         torch.cuda.synchronize()
         return fr, eq
 
-    rx_fn, rx_handle = ((L_.gfdm_hip_advanced_receiver_work_device, adv._h) if ic_iter else (L_.gfdm_hip_receiver_demodulate_device, dem._h))
-    rx_template = "k_row_receive<%d, %d, %d, %d, %d, %s>" % (K, M, L, 2 if ic_iter else 1, 1 if use_eq else 0, "true" if ic_iter else "false")
+    rx_fn, sb_rx = ((L_.gfdm_hip_advanced_receiver_work_device, sb_adv) if ic_iter else (L_.gfdm_hip_receiver_demodulate_device, sb_dem))
+    # kernel name as rocprofv3 prints it; last argument = IcKind (2: cancellation rounds on the matrix cores, the form QPSK + RRC taps take)
+    rx_template = "k_row_receive<%d, %d, %d, %d, %d, %d>" % (K, M, L, 2 if ic_iter else 1, 1 if use_eq else 0, 2 if ic_iter else 0)
     mod_template = "k_row_modulate<%d, %d, %d, 0>" % (K, M, L)
 
     # ---- headline ----------------------------------------------------------------------------------------------------
@@ -413,31 +475,54 @@ def main():
     outs = [torch.empty(B, N, dtype=torch.complex64, device=dev) for _ in range(ns)]
     side = [torch.cuda.Stream(device=dev) for _ in range(S)]
 
-    def step_fns_on(stream_of_slot):
+    # cfg2's step is modulate + demodulate.  Demodulating the frames a step has just modulated reads 18.9 MB that may still sit in the
+    # 256 MiB Infinity Cache; the headline therefore demodulates the frames modulated `lag` steps EARLIER (>= 256 MiB of other traffic in
+    # between, the same stream, so the order holds): every step is still one modulate + one demodulate of a whole batch.  The same-slot
+    # ("hot") figure is reported beside it.
+    step_bytes = 32 * N * B if two_kernel else rx_bps * N * B
+    lag = 0
+    if two_kernel:
+        lag = S * max(1, -(-(256 << 20) // (step_bytes * S)))
+        if lag >= ns:
+            lag = 0                                        # ring too small to separate the two kernels (tiny --ring-mib): hot only
+
+    def step_fns_on(stream_of_slot, demod_lag=0):
         fns = []
         for s in range(ns):
             step = []
             if two_kernel:
-                step.append(raw_launcher(L_.gfdm_hip_modulator_work_device, mod._h, frames[s], [sym[s]], B, stream_of_slot(s)))
-            step.append(raw_launcher(rx_fn, rx_handle, outs[s], [frames[s], eqs[s]], B, stream_of_slot(s)))
+                step.append(sb_mod.prepare(L_.gfdm_hip_modulator_work_device, [frames[s]], [(sym[s],)], [B], [stream_of_slot(s)]))
+            r = (s - demod_lag) % ns
+            step.append(sb_rx.prepare(rx_fn, [outs[r]], [(frames[r], eqs[r])], [B], [stream_of_slot(s)]))
             fns.append(step)
         return fns
 
-    piped = step_fns_on(lambda s: side[s % S].cuda_stream)
+    if two_kernel:                                         # every ring slot holds modulated frames before anything is timed
+        for s in range(ns):
+            sb_mod.prepare(L_.gfdm_hip_modulator_work_device, [frames[s]], [(sym[s],)], [B], [stream])()
+        torch.cuda.synchronize()
+    piped = step_fns_on(lambda s: side[s % S].cuda_stream, lag)
     wall, _ = timed_loop(piped, a.steps, a.warmup, world, time_kernels=False)
     total_blocks, _, wall_max = sharding.reduce_stats(B * a.steps, zeros3(), wall, dev)
     value = total_blocks / wall_max
+    value_hot = None
+    if lag:
+        hot = step_fns_on(lambda s: side[s % S].cuda_stream, 0)
+        wall_h, _ = timed_loop(hot, a.steps, a.warmup, world, time_kernels=False)
+        hot_blocks, _, wall_h_max = sharding.reduce_stats(B * a.steps, zeros3(), wall_h, dev)
+        value_hot = hot_blocks / wall_h_max
+        del hot
     sustained = None
     if a.sustained_seconds > 0:
         nsus = max(a.steps, int(a.sustained_seconds / max(wall_max / a.steps, 1e-7)) + 1)
         wsus, _ = timed_loop(piped, nsus, 0, world, time_kernels=False)
         sus_blocks, _, wsus_max = sharding.reduce_stats(B * nsus, zeros3(), wsus, dev)
         sustained = {"seconds": wsus_max, "steps": nsus, "value": sus_blocks / wsus_max, "ms_per_step": wsus_max / nsus * 1e3}
-    single = step_fns_on(lambda s: stream)
+    single = step_fns_on(lambda s: stream, lag)
     wall1, kern_ms = timed_loop(single, a.steps, a.warmup, world, time_kernels=True)
     _, _, wall1_max = sharding.reduce_stats(0, zeros3(), wall1, dev)
     # output checksum of ring slot 0 (strong scaling: the union over the ranks is global blocks [0, total) whatever N is)
-    for f in single[0]:
+    for f in step_fns_on(lambda s: stream, 0)[0]:
         f()
     torch.cuda.synchronize()
     _, chk, _ = sharding.reduce_stats(0, sharding.output_checksum(outs[0]), 0.0, dev)
@@ -467,9 +552,12 @@ def main():
                                % (cfg["workload"], total_per_step if scaling == "strong" else B,
                                   "in total, sharded contiguously over the GPUs" if scaling == "strong" else "per GPU", ns, S),
                    "name": a.config, "block_size": N, "batch_per_gpu": B, "blocks_per_step_all_gpus": total_per_step, "streams": S,
-                   "sharding": "independent blocks per GPU (gfdm_amd.sharding.shard_range), no data-path collective"},
+                   "sharding": "independent blocks per GPU (gfdm_amd.sharding.ShardedBatch: one handle + stream per device, contiguous shards), no data-path collective"},
         "msym_per_s": value * N / 1e6,
         "value_single_stream": total_per_step * a.steps / wall1_max,
+        # cfg2: `value` demodulates frames modulated `demod_lag_steps` steps earlier (cold: >= 256 MiB of traffic in between);
+        # value_same_slot demodulates the frames its own step has just written (may be served by the Infinity Cache)
+        "demod_lag_steps": lag, "value_same_slot": value_hot,
         "sustained": sustained,
         "roofline": roofline,
         "roofline_kernels": rk,
@@ -565,10 +653,13 @@ def main():
                 fns[i % nsl][0]()
                 evs[i][1].record()
             torch.cuda.synchronize()
-            kms_med = float(np.median([x.elapsed_time(y) for x, y in evs]))
+            per_launch = sorted(x.elapsed_time(y) for x, y in evs)
+            kms_med = float(np.median(per_launch))
             gbps = bps_ * N * BL / (kms[0] * 1e-3) / 1e9
             large[name] = {"blocks_per_launch": BL, "blocks_per_s": BL * nst / w, "kernel_ms": kms[0],
-                           "kernel_ms_per_launch_median": kms_med,
+                           "kernel_ms_per_launch_median": kms_med, "kernel_ms_per_launch_min": per_launch[0], "kernel_ms_per_launch_max": per_launch[-1],
+                           "frac_of_hbm_peak_range": [bps_ * N * BL / (per_launch[-1] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                      bps_ * N * BL / (per_launch[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS],
                            "bytes_per_launch": bps_ * N * BL, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
             del fr, eq, o, fns
         result["large_batch"] = large

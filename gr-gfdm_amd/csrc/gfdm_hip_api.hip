@@ -3,6 +3,7 @@
 // device or a kernel launch is unavailable the call fails with an error code.
 #include "../../include/gfdm_hip.h"
 #include "gfdm_plan.h"
+#include "gfdm_rowgeom.h"
 #include "gfdm_tx.h"
 
 #include <cmath>
@@ -53,6 +54,8 @@ namespace {
 std::atomic<int> g_force_generic{ 0 };
 // gfdm_hip_set_jit: run-time instantiation (hiprtc) of the row-lane kernels for shapes outside the compiled list
 std::atomic<int> g_jit{ 1 };
+// gfdm_hip_set_ic_matrix_cores: handles created while it is 0 run every cancellation round on the vector ALU
+std::atomic<int> g_ic_mfma{ 1 };
 
 struct Plan {
     int device = 0;
@@ -152,6 +155,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     for (int m = 0; m < M; ++m) tables.push_back(make_float2(pl.h_ictaps[m].x / (float)M, pl.h_ictaps[m].y / (float)M));
     // g = IDFT_M(ic)/M in double: one IC round is d_new = d0 - g (*) (dec_{k-1} + dec_{k+1})  (gfdm_rowlane_impl.h)
     bool ic_real_sym = true;
+    std::vector<float> g_real(M);
     {
         const double two_pi = 6.283185307179586476925286766559;
         std::vector<double> gr(M), gi(M);
@@ -169,6 +173,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
         for (int r = 0; r < M; ++r) {
             if (std::fabs(gi[r]) > 1e-7 * gmax || std::fabs(gr[r] - gr[(M - r) % M]) > 1e-7 * gmax) ic_real_sym = false;
             tables.push_back(make_float2((float)gr[r], (float)gi[r]));
+            g_real[r] = (float)gr[r];
         }
     }
     unit_roots(tables, M);
@@ -182,6 +187,42 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
                 const double a = -two_pi * (double)(((int64_t)q * m) % N) / (double)N;
                 tables.push_back(make_float2((float)std::cos(a), (float)std::sin(a)));
             }
+    }
+
+    // Matrix-core form of the cancellation rounds (IcMfma, gfdm_rowlane_impl.h): the A operand of v_mfma_f32_16x16x32_f16, lane l holds
+    // A[row l & 15][k = 8 (l >> 4) + j], j < 8.  Row p = output timeslot; k < 16: high f16 term of a[p][r = k], k >= 16: the residual term of
+    // r = k - 16, with a[p][r] = -s g[(p - r) mod M] 2^e (s = 1/sqrt 2: the QPSK amplitude; e puts the largest entry near 2^8 so that the
+    // residual terms stay normal f16 numbers).  The decisions enter as +-2^-e, exact in f16.
+    size_t icA_off = 0;                     // (behind every other table: the pointers below are offsets into `tables`)
+    unsigned ic_sig = 0;
+    if (receiver && ic_real_sym && gfdm::rowgeom::ic_mfma(K, M) && g_ic_mfma.load()) {
+        const double s = (double)0.70710678118654752f;
+        double amax = 0.0;
+        for (int r = 0; r < M; ++r) amax = std::fmax(amax, std::fabs(s * (double)g_real[r]));
+        int e = 13;
+        if (amax > 0.0) e = 8 - (int)std::ceil(std::log2(amax));
+        e = e < -4 ? -4 : e > 13 ? 13 : e;
+        const double c = std::ldexp(1.0, e);
+        if (tables.size() & 1) tables.push_back(make_float2(0.f, 0.f));        // 16-byte alignment of the operand table
+        icA_off = tables.size();
+        for (int lane = 0; lane < 64; ++lane) {
+            _Float16 h[8];
+            for (int j = 0; j < 8; ++j) {
+                const int pr = lane & 15, k = 8 * (lane >> 4) + j, r = k & 15;
+                double a = 0.0;
+                if (pr < M && r < M) a = -s * (double)g_real[((pr - r) % M + M) % M] * c;
+                const _Float16 hi = (_Float16)a;
+                h[j] = (k < 16) ? hi : (_Float16)(a - (double)hi);
+            }
+            cf packed[2];
+            static_assert(sizeof packed == sizeof h, "8 f16 = 2 complex floats");
+            memcpy(packed, h, sizeof packed);
+            tables.insert(tables.end(), packed, packed + 2);
+        }
+        const _Float16 sig = (_Float16)std::ldexp(1.0, -e);
+        unsigned short bits;
+        memcpy(&bits, &sig, sizeof bits);
+        ic_sig = bits;
     }
 
     DeviceGuard guard(device);
@@ -199,6 +240,8 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     dp.ictaps_m = dp.ictaps + M;
     dp.icg = dp.ictaps_m + M;
     dp.ic_real_sym = ic_real_sym ? 1 : 0;
+    dp.icA = ic_sig ? static_cast<const void*>(pl.d_tables + icA_off) : nullptr;
+    dp.ic_sig = ic_sig;
     dp.wM = dp.icg + M;
     dp.wK = dp.wM + M;
     dp.wN = dp.wK + K;
@@ -441,6 +484,11 @@ int gfdm_hip_force_generic_family_for_testing(int enable)
 int gfdm_hip_set_jit(int enable)
 {
     return g_jit.exchange(enable ? 1 : 0);
+}
+
+int gfdm_hip_set_ic_matrix_cores(int enable)
+{
+    return g_ic_mfma.exchange(enable ? 1 : 0);
 }
 
 int gfdm_hip_jit_build_for_testing(int timeslots, int subcarriers, int overlap, int part)

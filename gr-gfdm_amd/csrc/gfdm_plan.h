@@ -25,6 +25,9 @@ struct DevicePlan {
     const cf* ictaps_m; // [M]   ic[m] / M (IC taps with the inverse-DFT scale folded in)
     const cf* icg;      // [M]   g = IDFT_M(ic) / M: circular-convolution form of one cancellation round
     int ic_real_sym;    // 1 when g is real and even (real, even prototype filter): only g[0..M/2].x is used
+    // matrix-core form of a cancellation round (gfdm_rowlane_impl.h, ICK_MFMA; QPSK decisions, g real, M <= 16):
+    const void* icA;    // [64 lanes][8 f16] A operand of v_mfma_f32_16x16x32_f16: the circulant -s g[(p - r) mod M] 2^e, split in two f16
+    unsigned ic_sig;    // f16 bits of 2^-e: magnitude of one QPSK decision in the B operand (0: no table, vector-ALU rounds only)
     const cf* wM;       // [M]   exp(-2 pi j p / M)
     const cf* wK;       // [K]   exp(-2 pi j q / K)
     const cf* wN;       // [N]   exp(-2 pi j r / N)
@@ -56,6 +59,13 @@ struct IcParams {
     const int* smap;           // [n_active] the subcarrier_map itself (order matters for the phase sum)
     RxIo io;
 };
+
+// the cancellation rounds run on the matrix cores (IcMfma, gfdm_rowlane_impl.h) when the handle carries the operand table (real even IC
+// kernel, shape covered: gfdm_rowgeom.h ic_mfma) and the decisions are QPSK sign tests without phase compensation
+inline bool ic_mfma_applies(const DevicePlan& p, const IcParams& ic)
+{
+    return p.ic_sig != 0 && p.icA != nullptr && ic.decision == 1 && ic.do_phase_compensation <= 0;
+}
 
 enum RxMode {
     RX_FD = 0,        // fft_[equalize_]filter_downsample: out = S

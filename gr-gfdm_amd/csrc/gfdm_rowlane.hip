@@ -3,6 +3,7 @@
 // the library is linked with --no-undefined, so a shape missing there fails the build).
 #include "gfdm_plan.h"
 #include "gfdm_tx.h"
+#include "gfdm_rowgeom.h"
 
 #define GFDM_ROW_SHAPES(X) \
     X(64, 9, 2)            \
@@ -28,6 +29,7 @@ namespace gfdm {
     RX_DECL(rowlane_rx0_##K_##_##M_##_##L_)                                                                                         \
     RX_DECL(rowlane_rx1_##K_##_##M_##_##L_)                                                                                         \
     RX_DECL(rowlane_rx2_##K_##_##M_##_##L_)                                                                                         \
+    RX_DECL(rowlane_rx4_##K_##_##M_##_##L_)                                                                                         \
     hipError_t rowlane_mod_##K_##_##M_##_##L_(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in,        \
                                               int64_t nblocks, hipStream_t s);                                                      \
     hipError_t rowlane_est_##K_##_##M_##_##L_(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s);
@@ -75,9 +77,12 @@ hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const
                                   const cf* f_eq, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    const int part = est ? 2 : (mode == RX_IC && ic.ic_iter > 0) ? 1 : 0;     // which translation unit holds the kernel (launch_rx)
+    const bool ic_rounds = (mode == RX_IC && ic.ic_iter > 0);
+    // which translation unit holds the kernel (launch_rx); 4: cancellation rounds on the matrix cores
+    const int part = (ic_rounds && ic_mfma_applies(p, ic) && rowgeom::ic_mfma(p.K, p.M)) ? 4 : est ? 2 : ic_rounds ? 1 : 0;
 #define X(K_, M_, L_)                                                                                              \
     if (p.K == K_ && p.M == M_ && p.L == L_) {                                                                    \
+        if (part == 4) return rowlane_rx4_##K_##_##M_##_##L_(p, ic, est, twT, mode, out, in, f_eq, nblocks, s);   \
         if (part == 2) return rowlane_rx2_##K_##_##M_##_##L_(p, ic, est, twT, mode, out, in, f_eq, nblocks, s);   \
         if (part == 1) return rowlane_rx1_##K_##_##M_##_##L_(p, ic, est, twT, mode, out, in, f_eq, nblocks, s);   \
         return rowlane_rx0_##K_##_##M_##_##L_(p, ic, est, twT, mode, out, in, f_eq, nblocks, s);                  \

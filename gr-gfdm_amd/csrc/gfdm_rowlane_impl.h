@@ -513,12 +513,126 @@ __device__ __forceinline__ cf decide_point(cf x, const IcParams& ic)
     return ic.points[idx];
 }
 
+
+// ---- the cancellation rounds on the matrix cores (ICK_MFMA) ------------------------------------------------------------------
+// One round is  d_new[k][p] = d0[k][p] - sum_r g[(p - r) mod M] (dec[k-1][r] + dec[k+1][r]):  per block a product of the M x M circulant
+// of g with an M x 2K matrix of decisions -- the one dense contraction of the receiver.  With QPSK decisions that matrix holds only
+// 0, +-s, +-2s: EXACT in f16.  So the product runs as  D = A B + C  on v_mfma_f32_16x16x32_f16 with
+//   A (16 x 32, per-handle table p.icA) = [ hi | mid ], the two-term f16 split of  -s g[(p - r) mod M] 2^e  (22 significant bits; the
+//     32-deep contraction holds both terms against the same 16 decision rows),
+//   B (32 x 16) = the decisions of 16 subcarriers and one component, sigma[k-1] + sigma[k+1] in units of 2^-e, both 8-row halves twice,
+//   C = d0, D = d_new in f32 (products of f16 values are exact in the f32 accumulator),
+// 8 MFMAs per wavefront (4 groups of 16 subcarriers x re / im) and round in place of M(M+1)/2 packed multiply-adds, M(M-1)/2 packed
+// adds and the neighbour moves of the vector-ALU form: at M = 15 the two rounds of BASELINE configs[3] drop from ~1100 vector issue slots
+// per wave to ~250 plus 16 MFMAs that run beside the other waves' vector work.
+// Layouts: C / D lane (cn = lane & 15, cr = lane >> 4) holds subcarrier 16 gi + cn, timeslots 4 cr .. 4 cr + 3; the B operand wants
+// timeslots 8 (cr & 1) .. + 7 of the NEIGHBOUR subcarriers, so the decisions cross LDS once per round as an f16 image
+// [component][half][K][8] in the block's own tile (written 8 bytes, read 16 bytes per lane, conflict free), d0 / the result cross it
+// once before / after the rounds.  Rows p >= M of the 16 x 16 tile are padding: A is zero there, the image holds finite values.
+enum IcKind { ICK_GENERAL = 0, ICK_REALSYM = 1, ICK_MFMA = 2 };
+
+typedef _Float16 ic_h8 __attribute__((ext_vector_type(8)));
+typedef float ic_f4 __attribute__((ext_vector_type(4)));
+
+template <int K, int M> struct IcMfma {
+    static constexpr int NH = rowgeom::ic_mfma_halves(M);
+    static constexpr int IMG = (int)rowgeom::ic_mfma_image(K, M);
+    static constexpr bool DB = !rowgeom::wave_local(K);       // two images: ONE workgroup barrier per round
+    struct Pre {
+        uint4 a;               // A operand of this lane
+        unsigned pos[4];       // per 16-subcarrier group: the decision magnitude 2^-e in both f16 halves, 0 on an inactive subcarrier
+    };
+
+    // requested with the other tables at the start of the kernel
+    static __device__ __forceinline__ void preload(Pre& pre, const DevicePlan& p, const IcParams& ic)
+    {
+        const int lane = threadIdx.x & 63, r0 = (threadIdx.x & ~63) + (lane & 15);
+        pre.a = reinterpret_cast<const uint4*>(p.icA)[lane];
+        static_for<0, 4>([&](auto gi) {
+            constexpr int g4 = decltype(gi)::value;
+            pre.pos[g4] = ic.active[(r0 + 16 * g4) & (K - 1)] ? p.ic_sig * 0x10001u : 0u;
+        });
+    }
+
+    // d: row q of the block after matched filter + inverse DFT.  Leaves the block after ic_iter rounds in its tile X, [k][M], synchronised.
+    template <int TS>
+    static __device__ __forceinline__ void rounds(unsigned char* smem, cf* X, int q, const cf (&d)[M], const Pre& pre, int ic_iter)
+    {
+        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = d[m]; });
+        block_sync<K>();
+        const int lane = threadIdx.x & 63, cn = lane & 15, cr = lane >> 4;
+        const int r0 = (threadIdx.x & ~63) + cn;
+        const ic_h8 afrag = __builtin_bit_cast(ic_h8, pre.a);
+        ic_f4 c0[4][2], cur[4][2];
+        static_for<0, 4>([&](auto gi) {
+            constexpr int g4 = decltype(gi)::value;
+            const int row = r0 + 16 * g4, n = row & (K - 1);
+            const cf* Xg = reinterpret_cast<const cf*>(smem) + (row / K) * TS;
+            static_for<0, 4>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const int pp = 4 * cr + i;
+                const cf v = Xg[n * M + (pp < M ? pp : M - 1)];       // padding rows: any finite value
+                c0[g4][0][i] = v.x; c0[g4][1][i] = v.y;
+                cur[g4][0][i] = v.x; cur[g4][1][i] = v.y;
+            });
+        });
+        block_sync<K>();                                      // everyone holds its part of d0: the tile becomes the decision image
+        for (int it = 0; it < ic_iter; ++it) {                                                           // adv:56-76
+            const int img_off = DB ? (it & 1) * IMG : 0;
+            static_for<0, 4>([&](auto gi) {
+                constexpr int g4 = decltype(gi)::value;
+                const int row = r0 + 16 * g4, n = row & (K - 1);
+                unsigned char* img = smem + (size_t)(row / K) * TS * sizeof(cf) + img_off;
+                const unsigned pos = pre.pos[g4], neg = pos ^ 0x80008000u;
+                static_for<0, 2>([&](auto ci) {
+                    constexpr int c = decltype(ci)::value;
+                    // constellation_qpsk::decision_maker: sign tests, zero -> negative point                   adv:109-123
+                    const unsigned s0 = cur[g4][c][0] > 0.f ? pos : neg, s1 = cur[g4][c][1] > 0.f ? pos : neg;
+                    const unsigned s2 = cur[g4][c][2] > 0.f ? pos : neg, s3 = cur[g4][c][3] > 0.f ? pos : neg;
+                    const uint2 w = make_uint2((s0 & 0xFFFFu) | (s1 & 0xFFFF0000u), (s2 & 0xFFFFu) | (s3 & 0xFFFF0000u));
+                    if (NH == 2 || cr < 2)
+                        *reinterpret_cast<uint2*>(img + ((c * NH + (NH == 2 ? (cr >> 1) : 0)) * K + n) * 16 + 8 * (cr & 1)) = w;
+                });
+            });
+            block_sync<K>();
+            static_for<0, 4>([&](auto gi) {
+                constexpr int g4 = decltype(gi)::value;
+                const int row = r0 + 16 * g4, n = row & (K - 1);
+                const unsigned char* img = smem + (size_t)(row / K) * TS * sizeof(cf) + img_off;
+                const int h = (NH == 2) ? (cr & 1) : 0;
+                static_for<0, 2>([&](auto ci) {
+                    constexpr int c = decltype(ci)::value;
+                    // neighbours k - 1 and k + 1 (wrap mod K)                                                   rx:274-299
+                    const ic_h8 below = *reinterpret_cast<const ic_h8*>(img + ((c * NH + h) * K + ((n + K - 1) & (K - 1))) * 16);
+                    const ic_h8 above = *reinterpret_cast<const ic_h8*>(img + ((c * NH + h) * K + ((n + 1) & (K - 1))) * 16);
+                    cur[g4][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, below + above, c0[g4][c], 0, 0, 0);
+                });
+            });
+            if constexpr (!DB) block_sync<K>();               // all neighbour reads done before the image is rewritten
+        }
+        if constexpr (DB) block_sync<K>();                    // the last image has been read by everyone: the tile takes the result
+        static_for<0, 4>([&](auto gi) {
+            constexpr int g4 = decltype(gi)::value;
+            const int row = r0 + 16 * g4, n = row & (K - 1);
+            cf* Xg = reinterpret_cast<cf*>(smem) + (row / K) * TS;
+            static_for<0, 4>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                if (4 * cr + i < M) Xg[n * M + 4 * cr + i] = mk(cur[g4][0][i], cur[g4][1][i]);
+            });
+        });
+        block_sync<K>();
+    }
+};
+
 // =====================================================================================================================
 // EQ: EqSource.  EQ_PREAMBLE runs the preamble channel estimator (gfdm_est.h) in front, on the block's own lanes: the two K-point
 // FFTs of the preamble halves reuse the subcarrier FFT on a [K][2] view of the tile, the smoothed estimate (<= K bins) stays in
 // LDS, and phase C interpolates it per bin -- the N-bin equaliser vector never exists in HBM (16 K bytes read instead of 8 N).
-template <int K, int M, int L, int MODE, int EQ, bool ICSYM>
-__global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
+// (ICK_MFMA: at least two waves per SIMD, i.e. at most 256 registers -- below that bound hipcc keeps the MFMA accumulators in ordinary
+// VGPRs, which the dead registers of the FFT phases provide; with the default bound it takes 64 AGPRs ON TOP: 108 + 64 registers = 2 waves
+// per SIMD instead of 120 = 4)
+template <int K, int M, int L, int MODE, int EQ, int ICK>
+__global__ __launch_bounds__(RowShape<K>::WG, (MODE == RX_IC && ICK == ICK_MFMA) ? 2 : 1) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
                                                                 cf* __restrict__ out, const cf* __restrict__ in,
                                                                 const cf* __restrict__ f_eq, int64_t nblocks)
 {
@@ -526,6 +640,9 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     constexpr int MS = (EQ == EQ_PREAMBLE) ? M + 2 : M;   // tile row stride: with EQ_PREAMBLE two extra columns carry the preamble halves
     using T = RowTile<K, MS>;
     constexpr int N = K * M;
+    constexpr bool ICSYM = (ICK == ICK_REALSYM);
+    constexpr bool ICMX = (MODE == RX_IC && ICK == ICK_MFMA);   // cancellation rounds on the matrix cores (IcMfma)
+    static_assert(!ICMX || rowgeom::ic_mfma(K, M), "IcMfma: K a power of two >= 16, 4 <= M <= 16");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int g = threadIdx.x / K, q = threadIdx.x - g * K;            // q doubles as row index k in phase D
     const int64_t blk = (int64_t)blockIdx.x * S::BPW + g;
@@ -551,7 +668,9 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     }
     auto tap = [&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (PRE_TAPS) return tapv[i]; else return p.taps[i]; };
     auto icg = [&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (PRE_TAPS && MODE == RX_IC) return icgv[i]; else return p.icg[i]; };
-    const int wgt = (MODE == RX_IC) ? ic.active[q] : 0;      // multiplicity of subcarrier k in subcarrier_map (0 = inactive)
+    const int wgt = (MODE == RX_IC && !ICMX) ? ic.active[q] : 0;      // multiplicity of subcarrier k in subcarrier_map (0 = inactive)
+    typename IcMfma<ICMX ? K : 16, ICMX ? M : 4>::Pre icpre;
+    if constexpr (ICMX) IcMfma<K, M>::preload(icpre, p, ic);
     const int rank_q = (MODE != RX_FD && ic.io.demap) ? ic.io.rank[q] : -1;
     // ... and the scalar settings the later phases branch on (kernel arguments, i.e. scalar loads at the point of use otherwise)
     const int io_demap = ic.io.demap, io_nout = ic.io.nout, io_per_timeslot = ic.io.per_timeslot, io_A = ic.io.A;
@@ -691,7 +810,9 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
     block_sync<K>();                                      // every lane has read its neighbour rows: the tile is free
     GFDM_STAMP(3);
 
-    if constexpr (MODE == RX_IC) {
+    if constexpr (ICMX) {
+        IcMfma<K, M>::template rounds<T::TS>(smem, X, q, d, icpre, ic_iter);
+    } else if constexpr (MODE == RX_IC) {
         // One cancellation round of the reference is  d_new = IDFT_M(S - ic (.) DFT_M(nb)) / M  with nb = dec_{k-1} + dec_{k+1}.
         // Both transforms are linear, so  d_new = d0 - g (*) nb  with d0 = IDFT_M(S)/M (already in d) and the M-tap circular
         // convolution kernel g = IDFT_M(ic)/M (host table p.icg).  For the usual real, even prototype filters ic is real and
@@ -801,6 +922,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
         // resource demapper fused into the store: only active subcarriers, in mapper order; for per-timeslot order the lanes of
         // one timeslot write consecutive output symbols, so no LDS staging is needed                     mapper:91-106,136-163
         const int a = rank_q;
+        if constexpr (ICMX) static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d[m] = X[q * M + m]; });
         if (valid && a >= 0) {
             cf* o = out + blk * (int64_t)io_nout;
             static_for<0, M>([&](auto mi) {
@@ -811,8 +933,10 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_receive(DevicePlan p, I
         }
     } else {
         // ---- output: row -> tile, linear read, coalesced store
-        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = (MODE == RX_FD) ? s[m] : d[m]; });
-        block_sync<K>();
+        if constexpr (!ICMX) {                              // (IcMfma leaves its result in the tile)
+            static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = (MODE == RX_FD) ? s[m] : d[m]; });
+            block_sync<K>();
+        }
         if (valid) {
             static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; st_stream(out, base + q + K * i, X[q + K * i]); });
         }
@@ -919,42 +1043,54 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
 #ifndef __HIPCC_RTC__
 // PART selects which receive kernels a translation unit instantiates (compile time is dominated by the largest shape):
 //   0  frequency-domain output and plain demodulation, equaliser none / vector
-//   1  interference cancellation, equaliser none / vector
-//   2  every mode with the equaliser estimated from the preamble inside the kernel (EQ_PREAMBLE)
+//   1  interference cancellation on the vector ALU (any constellation, phase compensation, complex IC kernel), equaliser none / vector
+//   2  every mode with the equaliser estimated from the preamble inside the kernel (EQ_PREAMBLE), IC rounds on the vector ALU
+//   4  interference cancellation with the rounds on the matrix cores (IcMfma: QPSK, real even IC kernel, no phase compensation),
+//      equaliser none / vector / preamble  (3 = the modulators)
 template <int K, int M, int L, int PART>
 hipError_t launch_rx(const DevicePlan& p, const IcParams& ic, const EstPlan* est, const cf* twT, int mode, cf* out, const cf* in, const cf* f_eq,
                      int64_t nblocks, hipStream_t st)
 {
-    constexpr size_t lds0 = row_lds_bytes<K, (PART == 2 ? M + 2 : M)>();      // EQ_PREAMBLE: two more tile columns
     static_assert(row_lds_bytes<K, M>() <= 64 * 1024, "row-lane tile exceeds the default dynamic LDS limit");
     const dim3 grid((unsigned)((nblocks + RowShape<K>::BPW - 1) / RowShape<K>::BPW)), block(RowShape<K>::WG);
     static const EstPlan kNoEst = {};
     const EstPlan& e = est ? *est : kNoEst;
-    const size_t lds = lds0 + (PART == 2 ? EstTile<K>::bytes : 0);
-#define GFDM_RX(MODE_, EQ_, SYM_)                                                                                                       \
+    const bool pre = (PART == 2) || (PART == 4 && est);                          // EQ_PREAMBLE: two more tile columns + the estimate behind the tiles
+    size_t lds = pre ? row_lds_bytes<K, M + 2>() + EstTile<K>::bytes : row_lds_bytes<K, M>();
+    if (PART == 4 && lds < rowgeom::ic_mfma_lds(K, M)) lds = rowgeom::ic_mfma_lds(K, M);
+#define GFDM_RX(MODE_, EQ_, ICK_)                                                                                                       \
     do {                                                                                                                            \
         if (lds > 64 * 1024) {      /* only the largest shape with the estimate behind its tile */                                 \
-            hipError_t err_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_row_receive<K, M, L, MODE_, EQ_, SYM_>),          \
+            hipError_t err_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_row_receive<K, M, L, MODE_, EQ_, ICK_>),          \
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
             if (err_ != hipSuccess) return err_;                                                                                    \
         }                                                                                                                           \
-        hipLaunchKernelGGL((k_row_receive<K, M, L, MODE_, EQ_, SYM_>), grid, block, lds, st, p, ic, e, twT, out, in, f_eq, nblocks); \
+        hipLaunchKernelGGL((k_row_receive<K, M, L, MODE_, EQ_, ICK_>), grid, block, lds, st, p, ic, e, twT, out, in, f_eq, nblocks); \
     } while (0)
     const bool ic_rounds = (mode == RX_IC && ic.ic_iter > 0);
-    if constexpr (PART == 2) {
+    if constexpr (PART == 4) {
+        if constexpr (rowgeom::ic_mfma(K, M)) {
+            if (!ic_rounds || !ic_mfma_applies(p, ic)) return hipErrorInvalidValue;
+            if (est) GFDM_RX(RX_IC, EQ_PREAMBLE, ICK_MFMA);
+            else if (f_eq) GFDM_RX(RX_IC, EQ_VECTOR, ICK_MFMA);
+            else GFDM_RX(RX_IC, EQ_NONE, ICK_MFMA);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else if constexpr (PART == 2) {
         if (!est) return hipErrorInvalidValue;
-        if (mode == RX_FD) GFDM_RX(RX_FD, EQ_PREAMBLE, false);
-        else if (!ic_rounds) GFDM_RX(RX_DEMOD, EQ_PREAMBLE, false);
-        else if (p.ic_real_sym) GFDM_RX(RX_IC, EQ_PREAMBLE, true);
-        else GFDM_RX(RX_IC, EQ_PREAMBLE, false);
+        if (mode == RX_FD) GFDM_RX(RX_FD, EQ_PREAMBLE, ICK_GENERAL);
+        else if (!ic_rounds) GFDM_RX(RX_DEMOD, EQ_PREAMBLE, ICK_GENERAL);
+        else if (p.ic_real_sym) GFDM_RX(RX_IC, EQ_PREAMBLE, ICK_REALSYM);
+        else GFDM_RX(RX_IC, EQ_PREAMBLE, ICK_GENERAL);
     } else if constexpr (PART == 1) {
         if (est || !ic_rounds) return hipErrorInvalidValue;
-        if (p.ic_real_sym) { if (f_eq) GFDM_RX(RX_IC, EQ_VECTOR, true); else GFDM_RX(RX_IC, EQ_NONE, true); }
-        else { if (f_eq) GFDM_RX(RX_IC, EQ_VECTOR, false); else GFDM_RX(RX_IC, EQ_NONE, false); }
+        if (p.ic_real_sym) { if (f_eq) GFDM_RX(RX_IC, EQ_VECTOR, ICK_REALSYM); else GFDM_RX(RX_IC, EQ_NONE, ICK_REALSYM); }
+        else { if (f_eq) GFDM_RX(RX_IC, EQ_VECTOR, ICK_GENERAL); else GFDM_RX(RX_IC, EQ_NONE, ICK_GENERAL); }
     } else {
         if (est || ic_rounds) return hipErrorInvalidValue;
-        if (mode == RX_FD) { if (f_eq) GFDM_RX(RX_FD, EQ_VECTOR, false); else GFDM_RX(RX_FD, EQ_NONE, false); }
-        else { if (f_eq) GFDM_RX(RX_DEMOD, EQ_VECTOR, false); else GFDM_RX(RX_DEMOD, EQ_NONE, false); }
+        if (mode == RX_FD) { if (f_eq) GFDM_RX(RX_FD, EQ_VECTOR, ICK_GENERAL); else GFDM_RX(RX_FD, EQ_NONE, ICK_GENERAL); }
+        else { if (f_eq) GFDM_RX(RX_DEMOD, EQ_VECTOR, ICK_GENERAL); else GFDM_RX(RX_DEMOD, EQ_NONE, ICK_GENERAL); }
     }
 #undef GFDM_RX
     return hipGetLastError();

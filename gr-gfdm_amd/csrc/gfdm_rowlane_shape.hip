@@ -1,5 +1,5 @@
 // Row-lane kernels of ONE shape and ONE part (gfdm_rowlane_impl.h): compiled by the Makefile once per entry of ROW_SHAPES and
-// per part with -DGFDM_SHAPE_K= -DGFDM_SHAPE_M= -DGFDM_SHAPE_L= -DGFDM_SHAPE_PART= (0, 1, 2: receive kernels, 3: modulators).
+// per part with -DGFDM_SHAPE_K= -DGFDM_SHAPE_M= -DGFDM_SHAPE_L= -DGFDM_SHAPE_PART= (0, 1, 2, 4: receive kernels, 3: modulators).
 #include "gfdm_rowlane_impl.h"
 
 #if !defined(GFDM_SHAPE_K) || !defined(GFDM_SHAPE_M) || !defined(GFDM_SHAPE_L) || !defined(GFDM_SHAPE_PART)

@@ -50,6 +50,7 @@ def lib():
         "gfdm_hip_device_count": (i32, []),
         "gfdm_hip_force_generic_family_for_testing": (i32, [i32]),
         "gfdm_hip_set_jit": (i32, [i32]),
+        "gfdm_hip_set_ic_matrix_cores": (i32, [i32]),
         "gfdm_hip_jit_build_for_testing": (i32, [i32, i32, i32, i32]),
         "gfdm_hip_version": (cp, []),
         "gfdm_hip_modulator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
@@ -222,6 +223,12 @@ def set_jit(enable):
     """gfdm_hip_set_jit: run-time (hiprtc) instantiation of the row-lane kernels for shapes outside the compiled list; returns the
     previous setting."""
     return bool(lib().gfdm_hip_set_jit(1 if enable else 0))
+
+
+def set_ic_matrix_cores(enable):
+    """gfdm_hip_set_ic_matrix_cores: handles created while this is off run the interference-cancellation rounds on the vector ALU
+    instead of the matrix cores; returns the previous setting."""
+    return bool(lib().gfdm_hip_set_ic_matrix_cores(1 if enable else 0))
 
 
 class _Kernel:

@@ -74,6 +74,12 @@ int gfdm_hip_force_generic_family_for_testing(int enable);
  * "rowlane_jit".  Enabled by default; gfdm_hip_set_jit(0) makes such handles use the generic kernel family instead (no compile
  * step, several times slower kernels).  Returns the previous setting.  If hiprtc is unavailable the generic family is used. */
 int gfdm_hip_set_jit(int enable);
+/* The interference-cancellation rounds of the advanced receiver (lib/advanced_receiver_kernel_cc.cc:56-76, lib/receiver_kernel_cc.cc:274-299)
+ * run on the matrix cores (v_mfma_f32_16x16x32_f16, decisions exact in f16, IC taps as a two-term f16 split: 22 significant bits) where
+ * that form applies: QPSK sign decisions, a real even IC kernel (any real, even prototype filter), no phase compensation, 4 .. 16
+ * timeslots and a power-of-two number of subcarriers >= 16 on the row-lane kernels.  Everything else -- and every handle created while
+ * this switch is 0 -- runs the rounds on the vector ALU (f32 throughout).  Enabled by default; returns the previous setting. */
+int gfdm_hip_set_ic_matrix_cores(int enable);
 /* TEST HOOK: compile (or find in the disk cache) part 0..4 (receive, receive + IC, preamble-equalised receive, modulate, estimator) of
  * the row-lane kernels for a shape through hiprtc WITHOUT loading it --
  * needs no GPU, so the CPU-side tests can check that the embedded kernel sources build. */

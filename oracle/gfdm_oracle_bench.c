@@ -23,7 +23,9 @@ enum { BENCH_MOD_DEMOD = 0, BENCH_DEMOD = 1, BENCH_DEMOD_IC = 2 };
 typedef struct {
     int M, K, L, ntaps, mode, use_eq, ic_iter, chunk, cpu;
     const float* taps;
-    double deadline;       /* CLOCK_MONOTONIC seconds */
+    double seconds;        /* length of the timed loop */
+    pthread_barrier_t* ready;   /* every worker (and the driver) waits here once its kernel object and buffers exist */
+    double* t_start;       /* CLOCK_MONOTONIC seconds at which the driver saw the barrier open: start of the timed region */
     long blocks;           /* out */
     int failed;            /* out */
 } worker_t;
@@ -51,23 +53,26 @@ static void* worker(void* arg)
     float* out = (float*)malloc(sizeof(float) * 2 * n);
     float* eq = w->use_eq ? (float*)malloc(sizeof(float) * 2 * n) : NULL;
     int* smap = (int*)malloc(sizeof(int) * (size_t)w->K);
-    if (!o || !sym || !frames || !out || !smap || (w->use_eq && !eq)) { w->failed = 1; return NULL; }
+    if (!o || !sym || !frames || !out || !smap || (w->use_eq && !eq)) w->failed = 1;
     uint64_t s = 0x9E3779B97F4A7C15ull * (uint64_t)(w->cpu + 2);
     const float a = 0.70710678f;
-    for (size_t i = 0; i < 2 * n; ++i) {               /* QPSK symbols */
+    for (size_t i = 0; i < 2 * n && !w->failed; ++i) { /* QPSK symbols */
         s = s * 6364136223846793005ull + 1442695040888963407ull;
         sym[i] = (s >> 40) & 1 ? a : -a;
     }
-    for (size_t i = 0; i < n && eq; ++i) {             /* a smooth, nowhere-small equaliser vector */
+    for (size_t i = 0; i < n && eq && !w->failed; ++i) {   /* a smooth, nowhere-small equaliser vector */
         const float ph = 6.2831853f * (float)(i % N) / (float)N;
         eq[2 * i] = 1.0f + 0.4f * cosf(ph);
         eq[2 * i + 1] = 0.3f * sinf(ph);
     }
-    for (int k = 0; k < w->K; ++k) smap[k] = k;
+    for (int k = 0; k < w->K && smap; ++k) smap[k] = k;
     const float pts[8] = { -a, -a, a, -a, -a, a, a, a };
-    gfdm_oracle_modulate(o, frames, sym, w->chunk);     /* receiver input: modulated frames (decisions well conditioned) */
+    if (!w->failed) gfdm_oracle_modulate(o, frames, sym, w->chunk);     /* receiver input: modulated frames (decisions well conditioned) */
+    /* set-up (kernel object, buffers, input generation) is NOT timed: the clock starts when every worker has reached this point */
+    pthread_barrier_wait(w->ready);
+    const double deadline = now_s() + w->seconds;
     long done = 0;
-    do {
+    if (!w->failed) do {
         if (w->mode == BENCH_MOD_DEMOD) {
             gfdm_oracle_modulate(o, frames, sym, w->chunk);
             gfdm_oracle_demodulate(o, out, frames, eq, w->chunk);
@@ -77,17 +82,18 @@ static void* worker(void* arg)
             gfdm_oracle_advanced_receive(o, out, frames, eq, w->chunk, smap, w->K, pts, 4, GFDM_ORACLE_DECIDE_QPSK, w->ic_iter, 0);
         }
         done += w->chunk;
-    } while (now_s() < w->deadline);
+    } while (now_s() < deadline);
     w->blocks = done;
     free(sym); free(frames); free(out); free(eq); free(smap);
-    gfdm_oracle_destroy(o);
+    if (o) gfdm_oracle_destroy(o);
     return NULL;
 }
 
 /* Runs `nthreads` workers for about `seconds`; thread t is pinned to cpus[t] (cpus == NULL: not pinned).
  * mode: 0 modulate + demodulate, 1 demodulate, 2 demodulate + ic_iter IC rounds (QPSK, all subcarriers active);
  * use_eq: with the per-block equaliser vector (generic_work_equalize).  chunk: blocks a worker processes between two looks at
- * the clock.  Returns the blocks processed by all workers (or -1), *elapsed_s = wall time from start to the last join. */
+ * the clock.  Returns the blocks processed by all workers (or -1), *elapsed_s = wall time from the moment every worker had finished
+ * its set-up (a pthread barrier) to the last join. */
 long gfdm_oracle_bench(int timeslots, int subcarriers, int overlap, const float* taps, int ntaps, int mode, int use_eq, int ic_iter,
                        int nthreads, const int* cpus, double seconds, int chunk, double* elapsed_s)
 {
@@ -95,12 +101,28 @@ long gfdm_oracle_bench(int timeslots, int subcarriers, int overlap, const float*
     worker_t* w = (worker_t*)calloc((size_t)nthreads, sizeof(worker_t));
     pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
     if (!w || !th) { free(w); free(th); return -1; }
-    const double t0 = now_s();
+    pthread_barrier_t ready;
+    int started = 0;
+    double t0 = 0.0;
     for (int t = 0; t < nthreads; ++t) {
         w[t] = (worker_t){ timeslots, subcarriers, overlap, ntaps, mode, use_eq, ic_iter, chunk, cpus ? cpus[t] : -1, taps,
-                           t0 + seconds + 0.05 /* thread start-up */, 0, 0 };
-        if (pthread_create(&th[t], NULL, worker, &w[t]) != 0) { w[t].failed = 1; th[t] = 0; }
+                           seconds, &ready, &t0, 0, 0 };
     }
+    /* the barrier counts the workers that really start + this thread */
+    if (pthread_barrier_init(&ready, NULL, (unsigned)nthreads + 1) != 0) { free(w); free(th); return -1; }
+    for (int t = 0; t < nthreads; ++t) {
+        if (pthread_create(&th[t], NULL, worker, &w[t]) != 0) break;
+        ++started;
+    }
+    if (started < nthreads) {          /* cannot open the barrier with fewer threads: give up cleanly */
+        for (int t = 0; t < started; ++t) pthread_cancel(th[t]);
+        for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+        pthread_barrier_destroy(&ready);
+        free(w); free(th);
+        return -1;
+    }
+    pthread_barrier_wait(&ready);
+    t0 = now_s();
     long total = 0;
     int failed = 0;
     for (int t = 0; t < nthreads; ++t) {
@@ -109,6 +131,7 @@ long gfdm_oracle_bench(int timeslots, int subcarriers, int overlap, const float*
         failed |= w[t].failed;
     }
     if (elapsed_s) *elapsed_s = now_s() - t0;
+    pthread_barrier_destroy(&ready);
     free(w); free(th);
     return failed ? -1 : total;
 }

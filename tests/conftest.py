@@ -26,7 +26,7 @@ def pytest_configure(config):
 def golden_names():
     """kernel-path fixtures (make_golden.py); the composite-transmitter fixtures (make_golden_tx.py) are tx_*"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("tx_", "est_", "ic_"))]
+    return [n for n in names if not n.startswith(("tx_", "est_", "ic_", "snr_"))]
 
 
 def ic_golden_names():
@@ -53,6 +53,20 @@ def load_est_golden(name):
     g = {k: z[k] for k in z.files}
     for k in ("M", "K", "A"):
         g[k] = int(g[k])
+    return g
+
+
+def snr_golden_names():
+    """estimate_snr known answers (make_golden_snr.py: the reference test's 4 dB case and pygfdm.simulation.estimate_snr0)"""
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "snr_*.npz")))
+
+
+def load_snr_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    for k in ("M", "K", "A"):
+        g[k] = int(g[k])
+    g["snr_db"] = float(g["snr_db"])
     return g
 
 
@@ -90,6 +104,16 @@ def rel_err(a, b):
     num = np.linalg.norm(a - b, axis=-1)
     den = np.linalg.norm(b, axis=-1)
     return float(np.max(num / np.maximum(den, 1e-30)))
+
+
+def check_err(tag, err, tol):
+    """assert err < tol; with GFDM_ERRLOG=<file> the measured error is also appended there ("tag err tol"), which is where the per-path
+    error table of DESIGN.md section 2 comes from (scratch/errlog_table.py)."""
+    log = os.environ.get("GFDM_ERRLOG")
+    if log:
+        with open(log, "a") as f:
+            f.write("%s %.3e %.1e\n" % (tag, err, tol))
+    assert err < tol, "%s: error %.3e exceeds %.1e" % (tag, err, tol)
 
 
 def max_abs_component(a, b):

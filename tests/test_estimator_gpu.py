@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import gfdm_ref as R
-from conftest import assert_places, est_golden_names, have_gpu, load_est_golden, rel_err
+from conftest import assert_places, check_err, est_golden_names, have_gpu, load_est_golden, rel_err
 from gfdm_amd.filters import get_frequency_domain_filter
 
 pytestmark = pytest.mark.gpu
@@ -152,6 +152,26 @@ def test_estimate_snr_against_oracle_and_known_level():
     assert abs(np.mean(snr) / (2 * 100.0 * K / A) - 1.0) < 0.1                   # 20 dB over the band, see test_oracle.py
 
 
+@pytest.mark.parametrize("name", __import__("conftest").snr_golden_names())
+def test_estimate_snr_reference_known_answer(name):
+    """The reference's own estimate_snr test (python/qa_python_bindings.py:492-529: a 1024 / 936-subcarrier preamble in noise at 4 dB,
+    estimate within 1 dB) and pygfdm.simulation.estimate_snr0 on the same vectors (tests/golden/make_golden_snr.py), through ctypes
+    and the pybind11 class."""
+    import gfdm_amd
+    import gfdm_python
+    from conftest import load_snr_golden
+    g = load_snr_golden(name)
+    est = gfdm_amd.ChannelEstimator(g["M"], g["K"], g["A"], True, 1, g["preamble"])
+    snr, cnrs = est.estimate_snr(g["rx_preambles"])
+    assert np.max(np.abs(snr / g["pygfdm_estimate_snr0"] - 1.0)) < 1e-4
+    limit = 1.0 if g["K"] >= 1024 else 2.0
+    assert np.max(np.abs(10 * np.log10(snr) - g["snr_db"])) < limit
+    assert np.allclose(cnrs.sum(axis=-1), g["A"] * snr, rtol=1e-4)
+    pest = gfdm_python.Preamble_channel_estimator(g["M"], g["K"], g["A"], True, 1, g["preamble"])
+    res = pest.estimate_snr(g["rx_preambles"][0])                 # the call of the reference test
+    assert abs(10 * np.log10(res) - g["snr_db"]) < limit and abs(res / g["pygfdm_estimate_snr0"][0] - 1.0) < 1e-4
+
+
 def test_estimator_argument_errors():
     import gfdm_amd
     pre = np.ones(128, complex)
@@ -223,10 +243,10 @@ def test_receivers_with_fused_estimator(M, K, L, A, dc_free):
         rx.set_channel_estimator(est)
         got = rx.demodulate_estimated(blocks, rx_pre)
         assert got.shape == (B, N)
-        assert rel_err(got, ref) < 2e-5
+        check_err("fused_est_%d_%d_%d" % (M, K, A), rel_err(got, ref), TOL)
         # the two-kernel chain on the GPU gives the same symbols
         two_step = rx.demodulate_equalize(blocks.astype(np.complex64), est.estimate_frame(rx_pre))
-        assert rel_err(got, two_step.reshape(B, N)) < 2e-5
+        check_err("fused_est_vs_chain_%d_%d_%d" % (M, K, A), rel_err(got, two_step.reshape(B, N)), TOL)
     assert np.max(np.abs(adv.demodulate_estimated(blocks, rx_pre).reshape(B, K, M)[:, smap, :] - d[:, smap, :])) < 0.45    # decisions all correct (coarse estimate at small K)
     # bursts: [junk | preamble cp | core preamble | cp | block | cs], one buffer for both pointers
     pcp, cp, cs = K // 4, K // 8 + 1, 3
@@ -240,7 +260,7 @@ def test_receivers_with_fused_estimator(M, K, L, A, dc_free):
         rx.configure_frames(blen, off, smap[::-1], True)
         got = rx.demodulate_estimated(bursts, bursts.ravel()[5 + pcp:], preamble_stride=blen)
         assert got.shape == (B, A * M)
-        assert rel_err(got, R.demap_from_resources(ref, M, K, smap, True)) < 2e-5
+        check_err("fused_est_burst_%d_%d_%d" % (M, K, A), rel_err(got, R.demap_from_resources(ref, M, K, smap, True)), TOL)
     est2 = gfdm_amd.ChannelEstimator(M + 1, K, A, dc_free, 1, pre)
     with pytest.raises(ValueError, match="estimator is for"):
         dem.set_channel_estimator(est2)
@@ -295,14 +315,14 @@ def test_fused_estimator_pybind_surface():
     dem.set_channel_estimator(est)
     got = dem.demodulate_estimated(blocks, rx_pre)
     assert got.shape == (B, N) and got.dtype == np.complex64
-    assert rel_err(got, R.demodulate(blocks, R.normalize_taps(taps, M), M, K, L, feq)) < 2e-5
+    check_err("fused_est_pybind_dem", rel_err(got, R.demodulate(blocks, R.normalize_taps(taps, M), M, K, L, feq)), TOL)
     adv = gfdm_python.AdvancedReceiver(M, K, L, taps, smap.tolist(), 2, gfdm_python.Constellation.qpsk(), 0)
     adv.configure_frames(N, 0, smap.tolist(), True, M)
     adv.set_channel_estimator(est)
     got = adv.demodulate_estimated(blocks, rx_pre)
     ref = R.advanced_receive(blocks, R.normalize_taps(taps, M), M, K, L, smap, R.qpsk_points(), 2, f_eq=feq, kind="qpsk")
     assert got.shape == (B, A * M)
-    assert rel_err(got, R.demap_from_resources(ref, M, K, smap, True)) < 2e-5
+    check_err("fused_est_pybind_adv", rel_err(got, R.demap_from_resources(ref, M, K, smap, True)), TOL)
     with pytest.raises(RuntimeError, match="rx_preamble size"):
         adv.demodulate_estimated(blocks, rx_pre[:2])
     adv.set_channel_estimator(None)
