@@ -28,6 +28,12 @@ public:
     /* sum |x|^2 over ninput_size samples (host-side helper, not on the hot path) */
     float calculate_signal_energy(const gfdm_complex* p_in, const int ninput_size);
 
+    /* addition: the GPU (HIP device ordinal) on which kernel objects constructed BY THE CALLING THREAD are created from now on;
+     * the reference constructors have no such argument, so it is a per-thread setting (default 0).  Returns the previous value.
+     * gfdm/sharded_batch.h uses it to put one kernel object on every GPU of a node. */
+    static int set_default_device(int device);
+    static int default_device();
+
 protected:
     /* translate a gfdm_hip status into the exception the reference would have thrown */
     static void throw_on_error(int status, const char* where);

@@ -1,5 +1,6 @@
 // gr::gfdm::add_cyclic_prefix_cc over the HIP C-ABI (replaces lib/add_cyclic_prefix_cc.cc of gr-gfdm).
 #include <gfdm/add_cyclic_prefix_cc.h>
+#include <gfdm/gfdm_kernel_utils.h>
 #include <gfdm_hip.h>
 
 #include <stdexcept>
@@ -26,7 +27,7 @@ add_cyclic_prefix_cc::add_cyclic_prefix_cc(int block_len, int cp_len, int cs_len
     : d_block_len(block_len), d_cp_len(cp_len), d_cs_len(cs_len), d_ramp_len(ramp_len), d_cyclic_shift(cyclic_shift), d_handle(nullptr)
 {
     raise(gfdm_hip_cyclic_prefixer_create(&d_handle, block_len, cp_len, cs_len, ramp_len, fp(window_taps.data()),
-                                          static_cast<int>(window_taps.size()), cyclic_shift, 0),
+                                          static_cast<int>(window_taps.size()), cyclic_shift, gfdm_kernel_utils::default_device()),
           "add_cyclic_prefix_cc");
 }
 

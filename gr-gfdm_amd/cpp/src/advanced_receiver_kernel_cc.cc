@@ -57,7 +57,7 @@ advanced_receiver_kernel_cc::advanced_receiver_kernel_cc(int timeslots, int subc
                                             static_cast<int>(frequency_taps.size()), subcarrier_map.data(),
                                             static_cast<int>(subcarrier_map.size()), ic_iter,
                                             reinterpret_cast<const float*>(pts.data()), static_cast<int>(pts.size()),
-                                            static_cast<int>(constellation->rule()), do_phase_compensation, 0),
+                                            static_cast<int>(constellation->rule()), do_phase_compensation, gfdm_kernel_utils::default_device()),
           "advanced_receiver_kernel_cc");
 }
 

@@ -12,6 +12,19 @@ float gfdm_kernel_utils::calculate_signal_energy(const gfdm_complex* p_in, const
     return static_cast<float>(acc);
 }
 
+namespace {
+thread_local int t_default_device = 0;
+}
+
+int gfdm_kernel_utils::set_default_device(int device)
+{
+    const int prev = t_default_device;
+    t_default_device = device;
+    return prev;
+}
+
+int gfdm_kernel_utils::default_device() { return t_default_device; }
+
 void gfdm_kernel_utils::throw_on_error(int status, const char* where)
 {
     if (status == GFDM_HIP_OK) return;

@@ -10,7 +10,7 @@ modulator_kernel_cc::modulator_kernel_cc(int n_timeslots, int n_subcarriers, int
 {
     throw_on_error(gfdm_hip_modulator_create(&d_handle, n_timeslots, n_subcarriers, overlap,
                                              reinterpret_cast<const float*>(frequency_taps.data()),
-                                             static_cast<int>(frequency_taps.size()), 0),
+                                             static_cast<int>(frequency_taps.size()), default_device()),
                    "modulator_kernel_cc");
 }
 

@@ -25,7 +25,7 @@ preamble_channel_estimator_cc::preamble_channel_estimator_cc(int timeslots, int 
       d_which_estimator(which_estimator), d_handle(nullptr)
 {
     raise(gfdm_hip_channel_estimator_create(&d_handle, timeslots, fft_len, active_subcarriers, is_dc_free ? 1 : 0, which_estimator,
-                                            fp(preamble.data()), static_cast<int>(preamble.size()), 0),
+                                            fp(preamble.data()), static_cast<int>(preamble.size()), default_device()),
           "preamble_channel_estimator_cc");
 }
 

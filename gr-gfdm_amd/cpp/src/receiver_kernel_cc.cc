@@ -17,7 +17,7 @@ receiver_kernel_cc::receiver_kernel_cc(int n_timeslots, int n_subcarriers, int o
       d_handle(nullptr)
 {
     throw_on_error(gfdm_hip_receiver_create(&d_handle, n_timeslots, n_subcarriers, overlap, fp(frequency_taps.data()),
-                                            static_cast<int>(frequency_taps.size()), 0),
+                                            static_cast<int>(frequency_taps.size()), default_device()),
                    "receiver_kernel_cc");
 }
 

@@ -1,5 +1,6 @@
 // gr::gfdm::resource_mapper_kernel_cc over the HIP C-ABI (replaces lib/resource_mapper_kernel_cc.cc of gr-gfdm).
 #include <gfdm/resource_mapper_kernel_cc.h>
+#include <gfdm/gfdm_kernel_utils.h>
 #include <gfdm_hip.h>
 
 #include <stdexcept>
@@ -28,7 +29,7 @@ resource_mapper_kernel_cc::resource_mapper_kernel_cc(int timeslots, int subcarri
       d_is_mapper(is_mapper), d_handle(nullptr)
 {
     raise(gfdm_hip_resource_mapper_create(&d_handle, timeslots, subcarriers, active_subcarriers, subcarrier_map.data(),
-                                          static_cast<int>(subcarrier_map.size()), per_timeslot ? 1 : 0, 0),
+                                          static_cast<int>(subcarrier_map.size()), per_timeslot ? 1 : 0, gfdm_kernel_utils::default_device()),
           "resource_mapper_kernel_cc");
 }
 

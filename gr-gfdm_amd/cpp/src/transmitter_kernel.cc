@@ -38,7 +38,7 @@ transmitter_kernel::transmitter_kernel(int timeslots, int subcarriers, int activ
                                       subcarrier_map.data(), static_cast<int>(subcarrier_map.size()), per_timeslot ? 1 : 0, overlap,
                                       fp(frequency_taps.data()), static_cast<int>(frequency_taps.size()), fp(window_taps.data()),
                                       static_cast<int>(window_taps.size()), cyclic_shifts.data(), static_cast<int>(cyclic_shifts.size()),
-                                      fp(flat.data()), static_cast<int>(plen), 0),
+                                      fp(flat.data()), static_cast<int>(plen), gfdm_kernel_utils::default_device()),
           "transmitter_kernel");
 }
 

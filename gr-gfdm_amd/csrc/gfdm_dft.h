@@ -200,7 +200,18 @@ template <int P, bool INV> struct PrimeDft {
     }
 };
 
-// general N: prime -> direct, composite -> Cooley-Tukey  n = s + S r,  k = k1 + R k2
+constexpr int gcd_of(int a, int b) { return b == 0 ? a : gcd_of(b, a % b); }
+constexpr int inverse_mod(int a, int m)                                       // a^-1 mod m (a, m coprime)
+{
+    for (int i = 1; i < m; ++i)
+        if ((a * i) % m == 1) return i;
+    return 1;
+}
+
+// general N: prime -> direct; N = R S with coprime factors -> prime-factor algorithm (Good-Thomas: the index maps
+// n = (S n1 + R n2) mod N, k = (S S' k1 + R R' k2) mod N with S S' = 1 mod R, R R' = 1 mod S turn the N-point transform into an R x S
+// two-dimensional one WITHOUT twiddle factors -- 15 = 3 x 5 saves eight complex multiplies, and the maps are compile-time
+// register renaming); otherwise Cooley-Tukey  n = s + S r,  k = k1 + R k2
 template <int N, bool INV> struct Dft {
     static constexpr int R = smallest_factor(N);
     static constexpr int S = N / R;
@@ -208,6 +219,23 @@ template <int N, bool INV> struct Dft {
     {
         if constexpr (R == N) {
             PrimeDft<N, INV>::run(x);
+        } else if constexpr (gcd_of(R, S) == 1) {
+            constexpr int Si = inverse_mod(S % R, R), Ri = inverse_mod(R % S, S);
+            cf y[N];                                   // y[n2 * R + k1]
+            static_for<0, S>([&](auto si) {
+                constexpr int n2 = decltype(si)::value;
+                cf t[R];
+                static_for<0, R>([&](auto ri) { constexpr int n1 = decltype(ri)::value; t[n1] = x[(S * n1 + R * n2) % N]; });
+                Dft<R, INV>::run(t);
+                static_for<0, R>([&](auto ki) { constexpr int k1 = decltype(ki)::value; y[n2 * R + k1] = t[k1]; });
+            });
+            static_for<0, R>([&](auto ki) {
+                constexpr int k1 = decltype(ki)::value;
+                cf t[S];
+                static_for<0, S>([&](auto si) { constexpr int n2 = decltype(si)::value; t[n2] = y[n2 * R + k1]; });
+                Dft<S, INV>::run(t);
+                static_for<0, S>([&](auto k2i) { constexpr int k2 = decltype(k2i)::value; x[(S * Si * k1 + R * Ri * k2) % N] = t[k2]; });
+            });
         } else {
             cf y[N];                                   // y[s*R + k1]
             static_for<0, S>([&](auto si) {

@@ -53,8 +53,11 @@ namespace {
 // test hook (gfdm_hip_force_generic_family_for_testing): handles created while it is set use the generic kernel family
 std::atomic<int> g_force_generic{ 0 };
 // gfdm_hip_set_jit: run-time instantiation (hiprtc) of the row-lane kernels for shapes outside the compiled list
-std::atomic<int> g_jit{ 1 };
-// gfdm_hip_set_ic_matrix_cores: handles created while it is 0 run every cancellation round on the vector ALU
+//   0 off, 1 compile inside the constructor, 2 compile on a background thread (the handle starts on the generic family and switches over),
+//   3 (default) = 1 when the code objects are in the disk cache or the shape compiles quickly (timeslots <= 16), else 2
+std::atomic<int> g_jit{ 3 };
+// gfdm_hip_set_ic_matrix_cores: 0 = handles created meanwhile run every cancellation round on the vector ALU, 1 (default) = matrix cores where
+// they are the faster form (gfdm_rowgeom.h ic_mfma_preferred), 2 = matrix cores wherever the form applies
 std::atomic<int> g_ic_mfma{ 1 };
 
 struct Plan {
@@ -73,6 +76,21 @@ struct Plan {
     std::string kernel_name;
     const cf* d_twT = nullptr;       // [M][K] twiddles W_N^{q m}, transposed so that lane q reads them coalesced (row-lane family)
     int family = gfdm::FAMILY_GENERIC;
+    gfdm::JitCache jit;              // FAMILY_ROWLANE_JIT: this handle's pointers to the loaded kernel parts (no lock on the launch path)
+    // run-time instantiation in the background (gfdm_hip_set_jit modes 2 / 3): 0 compiling, 1 ready, -1 failed.  While it is 0 the handle
+    // runs on the generic family; the first call that sees 1 switches the handle over (a handle is used by one thread at a time)
+    std::shared_ptr<std::atomic<int>> jit_pending;
+
+    // the family to launch with right now
+    int current_family()
+    {
+        if (jit_pending) {
+            const int st = jit_pending->load(std::memory_order_acquire);
+            if (st == 1) { family = gfdm::FAMILY_ROWLANE_JIT; kernel_name = "rowlane_jit"; }
+            if (st != 0) jit_pending.reset();
+        }
+        return family;
+    }
 
     ~Plan()
     {
@@ -195,7 +213,8 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     // residual terms stay normal f16 numbers).  The decisions enter as +-2^-e, exact in f16.
     size_t icA_off = 0;                     // (behind every other table: the pointers below are offsets into `tables`)
     unsigned ic_sig = 0;
-    if (receiver && ic_real_sym && gfdm::rowgeom::ic_mfma(K, M) && g_ic_mfma.load()) {
+    const int mx_mode = g_ic_mfma.load();
+    if (receiver && ic_real_sym && (mx_mode == 2 ? gfdm::rowgeom::ic_mfma(K, M) : mx_mode == 1 && gfdm::rowgeom::ic_mfma_preferred(K, M))) {
         const double s = (double)0.70710678118654752f;
         double amax = 0.0;
         for (int r = 0; r < M; ++r) amax = std::fmax(amax, std::fabs(s * (double)g_real[r]));
@@ -253,16 +272,32 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
         if (gfdm::rowlane_supports(M, K, L)) {
             pl.family = gfdm::FAMILY_ROWLANE;
         } else if (g_jit.load() && gfdm::jit_eligible(M, K, L)) {
-            // not in the compiled list: instantiate the row-lane kernels for this shape now (seconds, once per shape and machine --
-            // the code object is cached on disk).  Any failure (no hiprtc, no cache directory AND no compiler, ...) leaves the handle
-            // on the generic HIP family; the reason stays readable from gfdm_hip_last_error().
-            // Only the parts this kind of handle launches are prepared here (a modulator never compiles receiver kernels); anything
-            // else (the preamble-equalised receivers once an estimator is attached) loads when it is first needed.
+            // not in the compiled list: instantiate the row-lane kernels for this shape (seconds to a minute per part, once per shape and
+            // machine -- the code objects are cached on disk; gfdm_hip_precompile fills that cache ahead of time).  Any failure (no hiprtc,
+            // no compiler, ...) leaves the handle on the generic HIP family; the reason stays readable from gfdm_hip_last_error().
+            // Only the parts this kind of handle launches are prepared (a modulator never compiles receiver kernels).
             std::string why;
             DeviceGuard guard(device);
             if (jit_parts == 0) jit_parts = receiver ? (1u << gfdm::JIT_PART_RX) : (1u << gfdm::JIT_PART_MOD);
-            if (gfdm::jit_prepare(M, K, L, jit_parts, why)) pl.family = gfdm::FAMILY_ROWLANE_JIT;
-            else g_last_error = "run-time instantiation of the row-lane kernels failed, using the generic family: " + why;
+            int mode = g_jit.load();
+            if (mode == 3) {
+                bool cached = true;
+                for (int part = 0; part < gfdm::JIT_NUM_PARTS; ++part)
+                    if (((jit_parts >> part) & 1u) && !gfdm::jit_cached(M, K, L, part)) cached = false;
+                mode = (cached || M <= 16) ? 1 : 2;
+            }
+            // in the background only if the generic family can serve the shape meanwhile (two tiles of the block in LDS or global scratch)
+            if (mode == 2 && gfdm::generic_supports(M, K, false)) {
+                // a receiver may get a channel estimator attached later: its preamble-equalised kernels are built in the same go, so that
+                // the switch-over never leaves a compile for the first estimated call
+                const unsigned parts = jit_parts | (receiver ? (1u << gfdm::JIT_PART_RX_PREAMBLE) : 0u);
+                pl.jit_pending = std::make_shared<std::atomic<int>>(0);
+                gfdm::jit_prepare_async(M, K, L, parts, device, pl.jit_pending);
+            } else if (gfdm::jit_prepare(M, K, L, jit_parts, why)) {
+                pl.family = gfdm::FAMILY_ROWLANE_JIT;
+            } else {
+                g_last_error = "run-time instantiation of the row-lane kernels failed, using the generic family: " + why;
+            }
         }
     }
     pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : pl.family == gfdm::FAMILY_ROWLANE_JIT ? "rowlane_jit" : "generic_lds";
@@ -361,16 +396,25 @@ int run_device(Plan& pl, void* out, const void* in0, int64_t nblocks, Launch lau
 hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks,
                             hipStream_t s, const gfdm::EstPlan* est = nullptr)
 {
-    if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
-    if (pl.family == gfdm::FAMILY_ROWLANE_JIT) return gfdm::jit_launch_receive(pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    const int family = pl.current_family();
+    if (family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    if (family == gfdm::FAMILY_ROWLANE_JIT) return gfdm::jit_launch_receive(&pl.jit, pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
     return gfdm::launch_generic_receive(pl.dp, ic, est, mode, out, in, f_eq, nblocks, s);
 }
 
 hipError_t mod_launch(Plan& pl, const gfdm::TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
-    if (pl.family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_modulate(pl.dp, tx, pl.d_twT, out, in, nblocks, s);
-    if (pl.family == gfdm::FAMILY_ROWLANE_JIT) return gfdm::jit_launch_modulate(pl.dp, tx, pl.d_twT, out, in, nblocks, s);
+    const int family = pl.current_family();
+    if (family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_modulate(pl.dp, tx, pl.d_twT, out, in, nblocks, s);
+    if (family == gfdm::FAMILY_ROWLANE_JIT) return gfdm::jit_launch_modulate(&pl.jit, pl.dp, tx, pl.d_twT, out, in, nblocks, s);
     return gfdm::launch_generic_modulate(pl.dp, tx, out, in, nblocks, s);
+}
+
+// name of the family the handle launches with NOW (a background instantiation that has finished is picked up here as well)
+const char* plan_kernel_name(const Plan& pl)
+{
+    (void)const_cast<Plan&>(pl).current_family();
+    return pl.kernel_name.c_str();
 }
 
 const gfdm::TxParams kNoTx = {};
@@ -400,6 +444,7 @@ int frame_io_configure(FrameIo& f, const Plan& pl, int frame_len, int cp_len, co
     const int N = pl.dp.N, K = pl.dp.K, M = pl.dp.M;
     if (cp_len < 0 || frame_len < cp_len + N) return fail(GFDM_HIP_EINVAL, "frame_len must be at least cp_len + block size");
     if (n_map < 0 || n_map > K || (n_map > 0 && !smap)) return fail(GFDM_HIP_EINVAL, "bad subcarrier_map");
+    if (n_map > 32767) return fail(GFDM_HIP_EUNSUPPORTED, "more than 32767 active subcarriers (the rank table holds 16-bit positions)");
     std::vector<int> sorted(smap, smap + n_map);
     std::sort(sorted.begin(), sorted.end());                      // the reference constructor sorts the map (resource_mapper_kernel_cc.cc:55)
     if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(GFDM_HIP_EINVAL, "All entries in subcarrier_map MUST be unique!");
@@ -481,14 +526,28 @@ int gfdm_hip_force_generic_family_for_testing(int enable)
     return g_force_generic.exchange(enable ? 1 : 0);
 }
 
-int gfdm_hip_set_jit(int enable)
+int gfdm_hip_set_jit(int mode)
 {
-    return g_jit.exchange(enable ? 1 : 0);
+    return g_jit.exchange(mode < 0 ? 0 : mode > 3 ? 3 : mode);
 }
 
-int gfdm_hip_set_ic_matrix_cores(int enable)
+int gfdm_hip_precompile(int timeslots, int subcarriers, int overlap, unsigned parts)
 {
-    return g_ic_mfma.exchange(enable ? 1 : 0);
+    if (!gfdm::jit_eligible(timeslots, subcarriers, overlap))
+        return gfdm::rowlane_supports(timeslots, subcarriers, overlap) ? GFDM_HIP_OK      // compiled into the library: nothing to do
+                                                                        : fail(GFDM_HIP_EUNSUPPORTED, "shape is served by the generic kernel family: nothing to instantiate");
+    if (parts == 0) parts = (1u << gfdm::JIT_NUM_PARTS) - 1;
+    for (int part = 0; part < gfdm::JIT_NUM_PARTS; ++part) {
+        if (!((parts >> part) & 1u)) continue;
+        std::string why;
+        if (!gfdm::jit_build_only(timeslots, subcarriers, part == gfdm::JIT_PART_EST ? 2 : overlap, part, why)) return fail(GFDM_HIP_EHIP, why);
+    }
+    return GFDM_HIP_OK;
+}
+
+int gfdm_hip_set_ic_matrix_cores(int mode)
+{
+    return g_ic_mfma.exchange(mode < 0 ? 0 : mode > 2 ? 2 : mode);
 }
 
 int gfdm_hip_jit_build_for_testing(int timeslots, int subcarriers, int overlap, int part)
@@ -532,7 +591,7 @@ int gfdm_hip_modulator_filter_taps(const gfdm_hip_modulator* m, float* out)
     return GFDM_HIP_OK;
 }
 
-const char* gfdm_hip_modulator_kernel_name(const gfdm_hip_modulator* m) { return m ? m->plan.kernel_name.c_str() : ""; }
+const char* gfdm_hip_modulator_kernel_name(const gfdm_hip_modulator* m) { return m ? plan_kernel_name(m->plan) : ""; }
 
 int gfdm_hip_modulator_work_device(gfdm_hip_modulator* m, void* out, const void* in, int64_t nblocks, void* stream)
 {
@@ -585,7 +644,7 @@ int gfdm_hip_receiver_ic_filter_taps(const gfdm_hip_receiver* r, float* out)
     return GFDM_HIP_OK;
 }
 
-const char* gfdm_hip_receiver_kernel_name(const gfdm_hip_receiver* r) { return r ? r->plan.kernel_name.c_str() : ""; }
+const char* gfdm_hip_receiver_kernel_name(const gfdm_hip_receiver* r) { return r ? plan_kernel_name(r->plan) : ""; }
 
 int gfdm_hip_receiver_demodulate_device(gfdm_hip_receiver* r, void* out, const void* in, const void* f_eq, int64_t nblocks, void* stream)
 {
@@ -738,7 +797,7 @@ int gfdm_hip_advanced_receiver_get_phase_compensation(const gfdm_hip_advanced_re
 {
     return a ? a->ic.do_phase_compensation : GFDM_HIP_EINVAL;
 }
-const char* gfdm_hip_advanced_receiver_kernel_name(const gfdm_hip_advanced_receiver* a) { return a ? a->plan.kernel_name.c_str() : ""; }
+const char* gfdm_hip_advanced_receiver_kernel_name(const gfdm_hip_advanced_receiver* a) { return a ? plan_kernel_name(a->plan) : ""; }
 
 int gfdm_hip_advanced_receiver_work_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* f_eq, int64_t nblocks,
                                            void* stream)
@@ -887,8 +946,9 @@ int gfdm_hip_transmitter_create(gfdm_hip_transmitter** out, int timeslots, int s
         return fail(GFDM_HIP_EINVAL, "Number of cyclic shifts and number of preambles do not match!");
     if (preamble_len < 0 || (preamble_len > 0 && !preambles)) return fail(GFDM_HIP_EINVAL, "All preambles must have equal size!");
     for (int i = 0; i < n_cyclic_shifts; ++i)
-        if (cyclic_shifts[i] < 0 || cyclic_shifts[i] > cs_len || cp_len + cyclic_shifts[i] > N)
-            return fail(GFDM_HIP_EINVAL, "cyclic shift must lie in [0, cs_len] and cp_len + shift must not exceed the block");
+        if (cyclic_shifts[i] < 0 || cyclic_shifts[i] > cs_len || cp_len + cyclic_shifts[i] > N || cs_len - cyclic_shifts[i] > N)
+            return fail(GFDM_HIP_EINVAL, "cyclic shift must lie in [0, cs_len], cp_len + shift and cs_len - shift must not exceed the block");
+    if (A > 32767) return fail(GFDM_HIP_EUNSUPPORTED, "more than 32767 active subcarriers (the rank table holds 16-bit positions)");
 
     gfdm_hip_transmitter* t = new (std::nothrow) gfdm_hip_transmitter();
     if (!t) return fail(GFDM_HIP_ENOMEM, "out of host memory");
@@ -936,7 +996,7 @@ int gfdm_hip_transmitter_cyclic_shift(const gfdm_hip_transmitter* t, int port)
 {
     return (t && port >= 0 && port < t->tx.nports) ? t->tx.shifts[port] : GFDM_HIP_EINVAL;
 }
-const char* gfdm_hip_transmitter_kernel_name(const gfdm_hip_transmitter* t) { return t ? t->plan.kernel_name.c_str() : ""; }
+const char* gfdm_hip_transmitter_kernel_name(const gfdm_hip_transmitter* t) { return t ? plan_kernel_name(t->plan) : ""; }
 
 static int tx_check_nin(const gfdm_hip_transmitter* t, int ninput_size)
 {
@@ -1093,7 +1153,7 @@ int est_run_device(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, v
         if (c->plan.family == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
             return gfdm::launch_rowlane_estimate(c->ep, static_cast<cf*>(out), static_cast<const cf*>(in), nframes, static_cast<hipStream_t>(stream));
         if (c->plan.family == gfdm::FAMILY_ROWLANE_JIT && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
-            return gfdm::jit_launch_estimate(c->ep, static_cast<cf*>(out), static_cast<const cf*>(in), nframes, static_cast<hipStream_t>(stream));
+            return gfdm::jit_launch_estimate(&c->plan.jit, c->ep, static_cast<cf*>(out), static_cast<const cf*>(in), nframes, static_cast<hipStream_t>(stream));
         return gfdm::launch_estimate(c->ep, in_stage, out_stage, static_cast<cf*>(out), static_cast<const cf*>(in), nframes,
                                      static_cast<hipStream_t>(stream));
     });
@@ -1108,7 +1168,7 @@ int est_run_host(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, flo
         if (c->plan.family == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
             return gfdm::launch_rowlane_estimate(c->ep, o, i, nframes, s);
         if (c->plan.family == gfdm::FAMILY_ROWLANE_JIT && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
-            return gfdm::jit_launch_estimate(c->ep, o, i, nframes, s);
+            return gfdm::jit_launch_estimate(&c->plan.jit, c->ep, o, i, nframes, s);
         return gfdm::launch_estimate(c->ep, in_stage, out_stage, o, i, nframes, s);
     });
 }

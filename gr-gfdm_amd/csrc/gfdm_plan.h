@@ -93,14 +93,25 @@ hipError_t launch_rowlane_modulate(const DevicePlan& p, const TxParams& tx, cons
                                    hipStream_t s);
 hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const EstPlan* est, const cf* twT, int mode, cf* out, const cf* in,
                                   const cf* f_eq, int64_t nblocks, hipStream_t s);
-// ... and the same kernels instantiated at run time (gfdm_jit.hip); jit_prepare* compile / load on the CURRENT device
-hipError_t jit_launch_modulate(const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
-hipError_t jit_launch_receive(const DevicePlan& p, const IcParams& ic, const EstPlan* est, const cf* twT, int mode, cf* out, const cf* in,
-                              const cf* f_eq, int64_t nblocks, hipStream_t s);
-hipError_t jit_launch_estimate(const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s);
+// ... and the same kernels instantiated at run time (gfdm_jit.hip); jit_prepare* compile / load on the CURRENT device.
+// JitCache: a handle's own pointers to the loaded parts, resolved at the first launch of each part -- after that a launch takes no lock
+// and no map lookup (one acquire load).
 }  // namespace gfdm
+#include <atomic>
+#include <memory>
 #include <string>
 namespace gfdm {
+struct JitCache {
+    std::atomic<const void*> part[5];
+    JitCache() { for (auto& p : part) p.store(nullptr); }
+};
+hipError_t jit_launch_modulate(JitCache* cache, const DevicePlan& p, const TxParams& tx, const cf* twT, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+hipError_t jit_launch_receive(JitCache* cache, const DevicePlan& p, const IcParams& ic, const EstPlan* est, const cf* twT, int mode, cf* out, const cf* in,
+                              const cf* f_eq, int64_t nblocks, hipStream_t s);
+hipError_t jit_launch_estimate(JitCache* cache, const EstPlan& e, cf* out, const cf* in, int64_t nframes, hipStream_t s);
+bool jit_cached(int M, int K, int L, int part);               // the part's code object is in the disk cache
+// compile / load on a background thread; *state: 0 running, 1 ready, -1 failed
+void jit_prepare_async(int M, int K, int L, unsigned parts, int device, std::shared_ptr<std::atomic<int>> state);
 // error reporting shared by the translation units of the C-ABI (thread-local message behind gfdm_hip_last_error)
 int api_fail(int code, const std::string& msg);
 int api_fail_hip(hipError_t e, const char* what);

@@ -536,11 +536,19 @@ typedef float ic_f4 __attribute__((ext_vector_type(4)));
 
 template <int K, int M> struct IcMfma {
     static constexpr int NH = rowgeom::ic_mfma_halves(M);
-    static constexpr int IMG = (int)rowgeom::ic_mfma_image(K, M);
+    static constexpr int PS = (K + 2) * 16;                   // bytes of one [K + 2 rows][8 f16] plane: rows -1 and K are copies of K - 1 and 0
+    static constexpr int IMG = (int)rowgeom::ic_mfma_image(K, M);   // one image = 2 components x NH halves
+#ifndef GFDM_IC_SINGLE_IMAGE
     static constexpr bool DB = !rowgeom::wave_local(K);       // two images: ONE workgroup barrier per round
+#else
+    static constexpr bool DB = false;
+#endif
+    // group gi of a wavefront = its lanes' rows 16 gi .. 16 gi + 15: which block of the wavefront (K < 64) and which row inside it
+    static constexpr int grp_block(int gi) { return K < 64 ? (16 * gi) / K : 0; }
+    static constexpr int grp_row(int gi) { return K < 64 ? (16 * gi) % K : 16 * gi; }
     struct Pre {
         uint4 a;               // A operand of this lane
-        unsigned pos[4];       // per 16-subcarrier group: the decision magnitude 2^-e in both f16 halves, 0 on an inactive subcarrier
+        float sig[4];          // per 16-subcarrier group: the decision magnitude 2^-e, 0 on an inactive subcarrier
     };
 
     // requested with the other tables at the start of the kernel
@@ -548,10 +556,21 @@ template <int K, int M> struct IcMfma {
     {
         const int lane = threadIdx.x & 63, r0 = (threadIdx.x & ~63) + (lane & 15);
         pre.a = reinterpret_cast<const uint4*>(p.icA)[lane];
+        const float sig = (float)__builtin_bit_cast(_Float16, (unsigned short)p.ic_sig);      // 2^-e, carried as its f16 bit pattern
         static_for<0, 4>([&](auto gi) {
             constexpr int g4 = decltype(gi)::value;
-            pre.pos[g4] = ic.active[(r0 + 16 * g4) & (K - 1)] ? p.ic_sig * 0x10001u : 0u;
+            pre.sig[g4] = ic.active[(r0 + 16 * g4) & (K - 1)] ? sig : 0.f;
         });
+    }
+
+    // constellation_qpsk::decision_maker (sign tests, zero -> negative point; adv:109-123) on two values, as an f16 pair of +-sig:
+    // x * inf is +-inf, or NaN for x = +-0; v_med3_f32 returns the MINIMUM of its operands when one of them is NaN, so
+    // med3(x inf, -sig, sig) = sig for x > 0 and -sig for everything else -- two full-rate instructions per value and no condition code
+    static __device__ __forceinline__ unsigned decide2(float x0, float x1, float sig)
+    {
+        const float inf = __builtin_inff();
+        const float y0 = __builtin_amdgcn_fmed3f(x0 * inf, -sig, sig), y1 = __builtin_amdgcn_fmed3f(x1 * inf, -sig, sig);
+        return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(y0, y1));
     }
 
     // d: row q of the block after matched filter + inverse DFT.  Leaves the block after ic_iter rounds in its tile X, [k][M], synchronised.
@@ -561,65 +580,82 @@ template <int K, int M> struct IcMfma {
         static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = d[m]; });
         block_sync<K>();
         const int lane = threadIdx.x & 63, cn = lane & 15, cr = lane >> 4;
-        const int r0 = (threadIdx.x & ~63) + cn;
+        const int wrow = threadIdx.x & ~63;                   // first row of this wavefront in the workgroup's lane space
+        const int n0 = (K < 64) ? cn : ((wrow & (K - 1)) + cn);   // row of group 0's lane inside its block
+        unsigned char* blk0 = smem + (size_t)(wrow / K) * TS * sizeof(cf);     // tile of the wavefront's first block
         const ic_h8 afrag = __builtin_bit_cast(ic_h8, pre.a);
+        // d0 in the C / D layout: timeslots 4 cr .. 4 cr + 3 of subcarrier n0 + 16 gi, real and imaginary parts apart.  (Timeslots >= M
+        // read whatever follows in the tile: padding rows of the 16 x 16 product, never stored.)
         ic_f4 c0[4][2], cur[4][2];
-        static_for<0, 4>([&](auto gi) {
-            constexpr int g4 = decltype(gi)::value;
-            const int row = r0 + 16 * g4, n = row & (K - 1);
-            const cf* Xg = reinterpret_cast<const cf*>(smem) + (row / K) * TS;
-            static_for<0, 4>([&](auto ii) {
-                constexpr int i = decltype(ii)::value;
-                const int pp = 4 * cr + i;
-                const cf v = Xg[n * M + (pp < M ? pp : M - 1)];       // padding rows: any finite value
-                c0[g4][0][i] = v.x; c0[g4][1][i] = v.y;
-                cur[g4][0][i] = v.x; cur[g4][1][i] = v.y;
+        {
+            const float* xf = reinterpret_cast<const float*>(blk0) + 2 * (n0 * M + 4 * cr);
+            static_for<0, 4>([&](auto gi) {
+                constexpr int g4 = decltype(gi)::value;
+                constexpr int off = grp_block(g4) * TS * 2 + grp_row(g4) * M * 2;          // in floats
+                static_for<0, 4>([&](auto ii) {
+                    constexpr int i = decltype(ii)::value;
+                    c0[g4][0][i] = xf[off + 2 * i];
+                    c0[g4][1][i] = xf[off + 2 * i + 1];
+                });
+                cur[g4][0] = c0[g4][0];
+                cur[g4][1] = c0[g4][1];
             });
-        });
+        }
         block_sync<K>();                                      // everyone holds its part of d0: the tile becomes the decision image
+        // image addresses: ONE base per lane for the writes and one for the reads, everything else is an immediate offset
+        //   write: row n + 1 (rows 0 and K + 1 are the wrap-around copies), half cr >> 1, timeslots 4 (cr & 1) .. + 3 of that half
+        //   read:  rows n and n + 2 (= subcarriers n - 1 and n + 1), half cr & 1
+        unsigned char* wbase = blk0 + (NH == 2 ? (cr >> 1) * PS : 0) + (n0 + 1) * 16 + 8 * (cr & 1);
+        const unsigned char* rbase = blk0 + (NH == 2 ? (cr & 1) * PS : 0) + n0 * 16;
+        const bool wave_first = (K <= 64) || ((wrow & (K - 1)) == 0), wave_last = (K <= 64) || ((wrow & (K - 1)) == K - 64);
         for (int it = 0; it < ic_iter; ++it) {                                                           // adv:56-76
             const int img_off = DB ? (it & 1) * IMG : 0;
             static_for<0, 4>([&](auto gi) {
                 constexpr int g4 = decltype(gi)::value;
-                const int row = r0 + 16 * g4, n = row & (K - 1);
-                unsigned char* img = smem + (size_t)(row / K) * TS * sizeof(cf) + img_off;
-                const unsigned pos = pre.pos[g4], neg = pos ^ 0x80008000u;
+                constexpr int goff = grp_block(g4) * TS * (int)sizeof(cf) + grp_row(g4) * 16;
+                const float sig = pre.sig[g4];
                 static_for<0, 2>([&](auto ci) {
                     constexpr int c = decltype(ci)::value;
-                    // constellation_qpsk::decision_maker: sign tests, zero -> negative point                   adv:109-123
-                    const unsigned s0 = cur[g4][c][0] > 0.f ? pos : neg, s1 = cur[g4][c][1] > 0.f ? pos : neg;
-                    const unsigned s2 = cur[g4][c][2] > 0.f ? pos : neg, s3 = cur[g4][c][3] > 0.f ? pos : neg;
-                    const uint2 w = make_uint2((s0 & 0xFFFFu) | (s1 & 0xFFFF0000u), (s2 & 0xFFFFu) | (s3 & 0xFFFF0000u));
-                    if (NH == 2 || cr < 2)
-                        *reinterpret_cast<uint2*>(img + ((c * NH + (NH == 2 ? (cr >> 1) : 0)) * K + n) * 16 + 8 * (cr & 1)) = w;
+                    const uint2 w = make_uint2(decide2(cur[g4][c][0], cur[g4][c][1], sig), decide2(cur[g4][c][2], cur[g4][c][3], sig));
+                    if (NH == 2 || cr < 2) {
+                        unsigned char* dst = wbase + img_off + goff + c * NH * PS;
+                        *reinterpret_cast<uint2*>(dst) = w;
+                        // wrap-around copies: subcarrier 0 again behind K - 1, subcarrier K - 1 again in front of 0
+                        if constexpr (grp_row(g4) == 0) { if (wave_first && cn == 0) *reinterpret_cast<uint2*>(dst + K * 16) = w; }
+                        if constexpr (grp_row(g4) + 16 == K || (K >= 64 && g4 == 3)) { if (wave_last && cn == 15) *reinterpret_cast<uint2*>(dst - K * 16) = w; }
+                    }
                 });
             });
             block_sync<K>();
             static_for<0, 4>([&](auto gi) {
                 constexpr int g4 = decltype(gi)::value;
-                const int row = r0 + 16 * g4, n = row & (K - 1);
-                const unsigned char* img = smem + (size_t)(row / K) * TS * sizeof(cf) + img_off;
-                const int h = (NH == 2) ? (cr & 1) : 0;
+                constexpr int goff = grp_block(g4) * TS * (int)sizeof(cf) + grp_row(g4) * 16;
                 static_for<0, 2>([&](auto ci) {
                     constexpr int c = decltype(ci)::value;
-                    // neighbours k - 1 and k + 1 (wrap mod K)                                                   rx:274-299
-                    const ic_h8 below = *reinterpret_cast<const ic_h8*>(img + ((c * NH + h) * K + ((n + K - 1) & (K - 1))) * 16);
-                    const ic_h8 above = *reinterpret_cast<const ic_h8*>(img + ((c * NH + h) * K + ((n + 1) & (K - 1))) * 16);
+                    // neighbours k - 1 and k + 1 (wrap mod K through the copies)                                rx:274-299
+                    const unsigned char* src = rbase + img_off + goff + c * NH * PS;
+                    const ic_h8 below = *reinterpret_cast<const ic_h8*>(src);
+                    const ic_h8 above = *reinterpret_cast<const ic_h8*>(src + 32);
                     cur[g4][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, below + above, c0[g4][c], 0, 0, 0);
                 });
             });
             if constexpr (!DB) block_sync<K>();               // all neighbour reads done before the image is rewritten
         }
         if constexpr (DB) block_sync<K>();                    // the last image has been read by everyone: the tile takes the result
-        static_for<0, 4>([&](auto gi) {
-            constexpr int g4 = decltype(gi)::value;
-            const int row = r0 + 16 * g4, n = row & (K - 1);
-            cf* Xg = reinterpret_cast<cf*>(smem) + (row / K) * TS;
-            static_for<0, 4>([&](auto ii) {
-                constexpr int i = decltype(ii)::value;
-                if (4 * cr + i < M) Xg[n * M + 4 * cr + i] = mk(cur[g4][0][i], cur[g4][1][i]);
+        {
+            float* xf = reinterpret_cast<float*>(blk0) + 2 * (n0 * M + 4 * cr);
+            static_for<0, 4>([&](auto gi) {
+                constexpr int g4 = decltype(gi)::value;
+                constexpr int off = grp_block(g4) * TS * 2 + grp_row(g4) * M * 2;
+                static_for<0, 4>([&](auto ii) {
+                    constexpr int i = decltype(ii)::value;
+                    if (12 + i < M || 4 * cr + i < M) {            // (first form: known at compile time for every lane)
+                        xf[off + 2 * i] = cur[g4][0][i];
+                        xf[off + 2 * i + 1] = cur[g4][1][i];
+                    }
+                });
             });
-        });
+        }
         block_sync<K>();
     }
 };
@@ -632,7 +668,12 @@ template <int K, int M> struct IcMfma {
 // VGPRs, which the dead registers of the FFT phases provide; with the default bound it takes 64 AGPRs ON TOP: 108 + 64 registers = 2 waves
 // per SIMD instead of 120 = 4)
 template <int K, int M, int L, int MODE, int EQ, int ICK>
-__global__ __launch_bounds__(RowShape<K>::WG, (MODE == RX_IC && ICK == ICK_MFMA) ? 2 : 1) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
+#ifdef GFDM_K128_WAVES      /* A/B builds: ask for more waves per SIMD (fewer registers) on the K = 128 kernels */
+#define GFDM_RX_MIN_WAVES(K_, ICMX_) ((K_) == 128 ? GFDM_K128_WAVES : (ICMX_) ? 2 : 1)
+#else
+#define GFDM_RX_MIN_WAVES(K_, ICMX_) ((ICMX_) ? 2 : 1)
+#endif
+__global__ __launch_bounds__(RowShape<K>::WG, GFDM_RX_MIN_WAVES(K, MODE == RX_IC && ICK == ICK_MFMA)) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
                                                                 cf* __restrict__ out, const cf* __restrict__ in,
                                                                 const cf* __restrict__ f_eq, int64_t nblocks)
 {
@@ -1057,7 +1098,10 @@ hipError_t launch_rx(const DevicePlan& p, const IcParams& ic, const EstPlan* est
     const EstPlan& e = est ? *est : kNoEst;
     const bool pre = (PART == 2) || (PART == 4 && est);                          // EQ_PREAMBLE: two more tile columns + the estimate behind the tiles
     size_t lds = pre ? row_lds_bytes<K, M + 2>() + EstTile<K>::bytes : row_lds_bytes<K, M>();
+#ifndef GFDM_IC_SINGLE_IMAGE
     if (PART == 4 && lds < rowgeom::ic_mfma_lds(K, M)) lds = rowgeom::ic_mfma_lds(K, M);
+#endif
+    if (PART == 4) lds += 128;            // the padding rows of the 16 x 16 tiles read up to 11 values past the last row
 #define GFDM_RX(MODE_, EQ_, ICK_)                                                                                                       \
     do {                                                                                                                            \
         if (lds > 64 * 1024) {      /* only the largest shape with the estimate behind its tile */                                 \

@@ -12,6 +12,8 @@ GFDM_ROWLANE_MOD(GFDM_SHAPE_K, GFDM_SHAPE_M, GFDM_SHAPE_L)
 GFDM_ROWLANE_RX_PART(GFDM_SHAPE_K, GFDM_SHAPE_M, GFDM_SHAPE_L, GFDM_SHAPE_PART)
 #endif
 
-#if defined(GFDM_STAMPS) && GFDM_SHAPE_K == 64 && GFDM_SHAPE_M == 9 && GFDM_SHAPE_PART == 1
-extern "C" int gfdm_debug_set_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(gfdm::g_stamp_buf), &p, sizeof(p)); }
+#if defined(GFDM_STAMPS)      /* diagnostic build only (scratch/stamps.py): one setter per translation unit, each has its own g_stamp_buf */
+#define GFDM_STAMP_SETTER_I(K_, M_, L_, P_) extern "C" int gfdm_debug_set_stamp_buffer_##K_##_##M_##_##L_##_p##P_(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(gfdm::g_stamp_buf), &p, sizeof(p)); }
+#define GFDM_STAMP_SETTER(K_, M_, L_, P_) GFDM_STAMP_SETTER_I(K_, M_, L_, P_)
+GFDM_STAMP_SETTER(GFDM_SHAPE_K, GFDM_SHAPE_M, GFDM_SHAPE_L, GFDM_SHAPE_PART)
 #endif

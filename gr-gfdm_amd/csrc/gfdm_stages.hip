@@ -282,6 +282,7 @@ int gfdm_hip_resource_mapper_create(gfdm_hip_resource_mapper** out, int timeslot
     // the reference accepts an index EQUAL to `subcarriers` (mapper:65: '>' where '>=' is meant) and then writes one row past the grid
     if (smap.back() >= K) return api_fail(GFDM_HIP_EINVAL, "All subcarrier indices MUST be smaller than subcarriers!");
     if ((int64_t)M * K > (int64_t)1 << 30) return api_fail(GFDM_HIP_EINVAL, "frame too large");
+    if (A > 32767) return api_fail(GFDM_HIP_EUNSUPPORTED, "more than 32767 active subcarriers (the rank table holds 16-bit positions)");
 
     gfdm_hip_resource_mapper* m = new (std::nothrow) gfdm_hip_resource_mapper();
     if (!m) return api_fail(GFDM_HIP_ENOMEM, "out of host memory");
@@ -399,8 +400,9 @@ int gfdm_hip_cyclic_prefixer_create(gfdm_hip_cyclic_prefixer** out, int block_le
     }
     if (2 * (int64_t)ramp_len > window_len) return api_fail(GFDM_HIP_EINVAL, "ramp_len too large for the frame");
     // the reference copies in[block - cp - shift ...) and in[0, cs - shift): shifts outside [0, cs] or cp + shift > block read out of bounds there
-    if (cyclic_shift < 0 || cyclic_shift > cs_len || (int64_t)cp_len + cyclic_shift > block_len)
-        return api_fail(GFDM_HIP_EINVAL, "cyclic shift must lie in [0, cs_len] and cp_len + shift must not exceed the block");
+    // ... and so does a suffix longer than the block (in[0, cs - shift) with cs - shift > block)
+    if (cyclic_shift < 0 || cyclic_shift > cs_len || (int64_t)cp_len + cyclic_shift > block_len || (int64_t)cs_len - cyclic_shift > block_len)
+        return api_fail(GFDM_HIP_EINVAL, "cyclic shift must lie in [0, cs_len], cp_len + shift and cs_len - shift must not exceed the block");
     gfdm_hip_cyclic_prefixer* c = new (std::nothrow) gfdm_hip_cyclic_prefixer();
     if (!c) return api_fail(GFDM_HIP_ENOMEM, "out of host memory");
     int rc = c->ctx.open(device);
@@ -428,8 +430,8 @@ int gfdm_hip_cyclic_prefixer_cyclic_shift(const gfdm_hip_cyclic_prefixer* c) { r
 int gfdm_hip_cyclic_prefixer_add_device(gfdm_hip_cyclic_prefixer* c, void* out, const void* in, int cyclic_shift, int64_t nblocks, void* stream)
 {
     if (!c) return api_fail(GFDM_HIP_EINVAL, "NULL handle");
-    if (cyclic_shift < 0 || cyclic_shift > c->cs || c->cp + cyclic_shift > c->N)
-        return api_fail(GFDM_HIP_EINVAL, "cyclic shift must lie in [0, cs_len] and cp_len + shift must not exceed the block");
+    if (cyclic_shift < 0 || cyclic_shift > c->cs || c->cp + cyclic_shift > c->N || c->cs - cyclic_shift > c->N)
+        return api_fail(GFDM_HIP_EINVAL, "cyclic shift must lie in [0, cs_len], cp_len + shift and cs_len - shift must not exceed the block");
     if (nblocks < 0 || !out || !in) return api_fail(GFDM_HIP_EINVAL, "NULL buffer or negative block count");
     if (nblocks == 0) return GFDM_HIP_OK;
     DeviceGuard guard(c->ctx.device);

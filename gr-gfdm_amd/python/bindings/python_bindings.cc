@@ -118,11 +118,8 @@ py::array_t<cfloat> run_estimated(Kernel& self, const carray& x, const carray& p
 
 } // namespace
 
-void bind_testing(py::module_& m);   // testing_bindings.cc
-
 PYBIND11_MODULE(gfdm_python, m)
 {
-    bind_testing(m);
     m.doc() = "GFDM modulator / receiver kernels on AMD MI355X (HIP) behind gr-gfdm's kernel-class API";
 
     py::class_<modulator_kernel_cc>(m, "Modulator")

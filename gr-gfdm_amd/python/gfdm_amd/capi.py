@@ -50,6 +50,7 @@ def lib():
         "gfdm_hip_device_count": (i32, []),
         "gfdm_hip_force_generic_family_for_testing": (i32, [i32]),
         "gfdm_hip_set_jit": (i32, [i32]),
+        "gfdm_hip_precompile": (i32, [i32, i32, i32, ctypes.c_uint]),
         "gfdm_hip_set_ic_matrix_cores": (i32, [i32]),
         "gfdm_hip_jit_build_for_testing": (i32, [i32, i32, i32, i32]),
         "gfdm_hip_version": (cp, []),
@@ -219,16 +220,31 @@ class generic_family_for_testing:
         return False
 
 
-def set_jit(enable):
-    """gfdm_hip_set_jit: run-time (hiprtc) instantiation of the row-lane kernels for shapes outside the compiled list; returns the
-    previous setting."""
-    return bool(lib().gfdm_hip_set_jit(1 if enable else 0))
+JIT_OFF, JIT_IN_CONSTRUCTOR, JIT_BACKGROUND, JIT_AUTO = 0, 1, 2, 3
 
 
-def set_ic_matrix_cores(enable):
-    """gfdm_hip_set_ic_matrix_cores: handles created while this is off run the interference-cancellation rounds on the vector ALU
-    instead of the matrix cores; returns the previous setting."""
-    return bool(lib().gfdm_hip_set_ic_matrix_cores(1 if enable else 0))
+def set_jit(mode):
+    """gfdm_hip_set_jit: when the row-lane kernels of a shape outside the compiled list are instantiated (hiprtc) -- JIT_OFF never (generic
+    family), JIT_IN_CONSTRUCTOR, JIT_BACKGROUND (the handle starts on the generic family and switches over), JIT_AUTO (default: in the
+    constructor when cached or quick, else in the background).  True / False mean JIT_IN_CONSTRUCTOR / JIT_OFF.  Returns the previous mode."""
+    if mode is True:
+        mode = JIT_IN_CONSTRUCTOR
+    elif mode is False:
+        mode = JIT_OFF
+    return lib().gfdm_hip_set_jit(int(mode))
+
+
+def precompile(timeslots, subcarriers, overlap, parts=0):
+    """gfdm_hip_precompile: compile the tuned kernels of a shape into the disk cache without creating a handle (no GPU needed).
+    parts: bit mask (receive 1, receive + IC 2, preamble-equalised receive 4, modulate 8, estimator 16), 0 = all."""
+    _check(lib().gfdm_hip_precompile(int(timeslots), int(subcarriers), int(overlap), int(parts)))
+
+
+def set_ic_matrix_cores(mode):
+    """gfdm_hip_set_ic_matrix_cores: where handles created afterwards run the interference-cancellation rounds -- 0 / False vector ALU
+    only, 1 / True (default) matrix cores where they are the faster form (subcarriers >= 128), 2 matrix cores wherever the form applies.
+    Returns the previous mode."""
+    return lib().gfdm_hip_set_ic_matrix_cores(int(mode))
 
 
 class _Kernel:

@@ -1,8 +1,10 @@
-// gfdm_python._testing: hooks the tests use to drive C++-only surfaces of the drop-in classes.
+// gfdm_testing: a TEST-ONLY module (built next to gfdm_python, never imported by the product) with hooks the tests use to drive
+// C++-only surfaces of the drop-in classes.  Its functions take the kernel objects of gfdm_python (imported first).
 //   * a scheduler stand-in for the batched work() bodies of gfdm/batched_work.h: it calls them the way GNU Radio's scheduler
 //     calls a block's work() -- successive runs of `noutput_items`, pointers advanced by what work() returned
 //   * the reference's legacy 2-D receiver API (lib/receiver_kernel_cc.cc:130-163,194-209,227-272), which has no Python binding
 //     in the reference either, and gfdm_kernel_utils::calculate_signal_energy (lib/gfdm_kernel_utils.cc:59-65)
+//   * gfdm/sharded_batch.h (one batch over several devices), which is a C++ template with no Python surface of its own
 #include <pybind11/complex.h>
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
@@ -15,6 +17,7 @@
 #include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm/receiver_kernel_cc.h>
 #include <gfdm/resource_mapper_kernel_cc.h>
+#include <gfdm/sharded_batch.h>
 #include <gfdm/transmitter_kernel.h>
 
 namespace py = pybind11;
@@ -93,9 +96,51 @@ py::array_t<cfloat> from_matrix(const matrix_t& m)
 
 } // namespace
 
-void bind_testing(py::module_& m)
+PYBIND11_MODULE(gfdm_testing, t)
 {
-    py::module_ t = m.def_submodule("_testing", "test hooks: scheduler stand-in for gfdm/batched_work.h, legacy 2-D receiver API");
+    t.doc() = "test hooks: scheduler stand-in for gfdm/batched_work.h, legacy 2-D receiver API, gfdm/sharded_batch.h";
+    py::module_::import("gfdm_python");                  // the kernel classes the functions below take as arguments
+
+    // gfdm/sharded_batch.h: one host batch over `devices` (an ordinal may repeat: several handles on one GPU); returns (result, shards)
+    t.def("sharded_modulate", [](int M, int K, int L, const std::vector<cfloat>& taps, const std::vector<int>& devices, const carray& in_arr) {
+        sharded_batch<modulator_kernel_cc> sb(devices, M, K, L, taps);
+        py::buffer_info in = in_arr.request();
+        const long nblocks = in.size / sb.block_size();
+        py::array_t<cfloat> out(in.size);
+        {
+            py::gil_scoped_release nogil;
+            sb.generic_work_batch(static_cast<cfloat*>(out.request().ptr), static_cast<const cfloat*>(in.ptr), nblocks);
+        }
+        std::vector<std::pair<long, long>> shards;
+        for (int i = 0; i < sb.n_shards(); ++i) shards.push_back(sb.shard(nblocks, i));
+        return py::make_tuple(out, shards);
+    });
+    t.def("sharded_advanced_receive", [](int M, int K, int L, const std::vector<cfloat>& taps, const std::vector<int>& smap, int ic_iter,
+                                         const std::vector<int>& devices, const carray& in_arr, py::object eq_obj) {
+        sharded_batch<advanced_receiver_kernel_cc> sb(devices, M, K, L, taps, smap, ic_iter, constellation::qpsk(), 0);
+        py::buffer_info in = in_arr.request();
+        const long nblocks = in.size / sb.block_size();
+        carray eq_arr;
+        const cfloat* eq = nullptr;
+        if (!eq_obj.is_none()) { eq_arr = eq_obj.cast<carray>(); eq = static_cast<const cfloat*>(eq_arr.request().ptr); }
+        py::array_t<cfloat> out(in.size);
+        {
+            py::gil_scoped_release nogil;
+            sb.generic_work_batch(static_cast<cfloat*>(out.request().ptr), static_cast<const cfloat*>(in.ptr), eq, nblocks);
+        }
+        return out;
+    });
+    t.def("shard_range", [](long total, int index, int n) { return shard_range(total, index, n); });
+    t.def("default_device_is_per_thread", []() {
+        const int before = gfdm_kernel_utils::set_default_device(0);
+        int seen_in_thread = -1;
+        gfdm_kernel_utils::set_default_device(3);
+        std::thread th([&] { seen_in_thread = gfdm_kernel_utils::default_device(); });
+        th.join();
+        const bool ok = (seen_in_thread == 0) && gfdm_kernel_utils::default_device() == 3;
+        gfdm_kernel_utils::set_default_device(before);
+        return ok;
+    });
     t.def("scheduler_run", &run_sync<modulator_kernel_cc>, py::arg("kernel"), py::arg("stream"), py::arg("noutput_items"));
     t.def("scheduler_run", &run_sync<receiver_kernel_cc>, py::arg("kernel"), py::arg("stream"), py::arg("noutput_items"));
     t.def("scheduler_run_equalize", &run_sync_eq, py::arg("kernel"), py::arg("stream"), py::arg("eq_stream"), py::arg("noutput_items"));

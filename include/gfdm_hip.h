@@ -68,18 +68,31 @@ int gfdm_hip_force_generic_family_for_testing(int enable);
 /* Run-time instantiation of the tuned (row-lane) kernels for shapes outside the library's compiled list: a handle for a shape with
  * a power-of-two number of subcarriers (4 .. 1024) or one up to 1024 that is a product of two or three factors <= 32 (12, 20, 34, 48, 96, 100, 240, 384, 600, 1000 ...),
  * 3 .. 48 timeslots and overlap 2 .. 8 -- as far as the block fits the CU's 160 KB LDS (every shape up to 512 subcarriers does; 1024 x 17) -- gets the kernels compiled for exactly that
- * shape through hiprtc when it is created (1-10 s per part; a handle compiles only the parts of its kind -- a modulator the
- * modulator kernels, a receiver the receive kernels, ... -- the rest at first use; the code objects are cached under $GFDM_HIP_CACHE_DIR,
- * else $XDG_CACHE_HOME/gfdm_hip, else ~/.cache/gfdm_hip, so this happens once per shape and machine) and reports kernel_name
- * "rowlane_jit".  Enabled by default; gfdm_hip_set_jit(0) makes such handles use the generic kernel family instead (no compile
- * step, several times slower kernels).  Returns the previous setting.  If hiprtc is unavailable the generic family is used. */
-int gfdm_hip_set_jit(int enable);
+ * shape through hiprtc (1-70 s per part, growing with the number of timeslots; a handle compiles only the parts of its kind -- a modulator
+ * the modulator kernels, a receiver the receive kernels, ... -- the rest at first use; the code objects are cached under
+ * $GFDM_HIP_CACHE_DIR, else $XDG_CACHE_HOME/gfdm_hip, else ~/.cache/gfdm_hip -- a directory of this user that nobody else can write, or no
+ * cache at all -- so this happens once per shape and machine) and reports kernel_name "rowlane_jit".
+ * gfdm_hip_set_jit(mode) says WHEN the compile happens for handles created afterwards (returns the previous mode):
+ *   0  never: such shapes use the generic kernel family (no compile step, several times slower kernels);
+ *   1  inside the constructor, which then takes as long as the compile;
+ *   2  on a background thread: the constructor returns at once, the handle runs on the generic family (same results, kernel_name
+ *      "generic_lds") and switches to the tuned kernels -- kernel_name "rowlane_jit" -- at the first call after the build has finished;
+ *   3  (default) like 1 when the code objects are already in the disk cache or the shape compiles within seconds (timeslots <= 16),
+ *      like 2 otherwise: no constructor blocks for longer than a few seconds.
+ * If hiprtc is unavailable the generic family is used.  gfdm_hip_precompile fills the disk cache ahead of time. */
+int gfdm_hip_set_jit(int mode);
+/* Deployment step: compile the tuned kernels of a shape into the disk cache WITHOUT creating a handle (no GPU needed), so that the first
+ * flowgraph using the shape starts with them.  parts: bit 0 receive, 1 receive + IC, 2 preamble-equalised receive, 3 modulate,
+ * 4 estimator (0 = all).  Returns GFDM_HIP_OK also for shapes that are compiled into the library; GFDM_HIP_EUNSUPPORTED for shapes only
+ * the generic family serves.  Command line: python -m gfdm_amd.precompile <timeslots> <subcarriers> <overlap> [...]. */
+int gfdm_hip_precompile(int timeslots, int subcarriers, int overlap, unsigned parts);
 /* The interference-cancellation rounds of the advanced receiver (lib/advanced_receiver_kernel_cc.cc:56-76, lib/receiver_kernel_cc.cc:274-299)
- * run on the matrix cores (v_mfma_f32_16x16x32_f16, decisions exact in f16, IC taps as a two-term f16 split: 22 significant bits) where
- * that form applies: QPSK sign decisions, a real even IC kernel (any real, even prototype filter), no phase compensation, 4 .. 16
- * timeslots and a power-of-two number of subcarriers >= 16 on the row-lane kernels.  Everything else -- and every handle created while
- * this switch is 0 -- runs the rounds on the vector ALU (f32 throughout).  Enabled by default; returns the previous setting. */
-int gfdm_hip_set_ic_matrix_cores(int enable);
+ * can run on the matrix cores (v_mfma_f32_16x16x32_f16; the QPSK decisions are exact in f16, the IC taps enter as a two-term f16 split with
+ * 22 significant bits, sums in f32) where that form applies: QPSK sign decisions, a real even IC kernel (any real, even prototype filter),
+ * no phase compensation, 4 .. 16 timeslots and a power-of-two number of subcarriers >= 16 on the row-lane kernels.  Mode of the handles
+ * created afterwards (returns the previous mode): 0 = vector ALU only (f32 throughout), 1 (default) = matrix cores where they are the
+ * faster form (blocks of two or more wavefronts: subcarriers >= 128), 2 = matrix cores wherever the form applies. */
+int gfdm_hip_set_ic_matrix_cores(int mode);
 /* TEST HOOK: compile (or find in the disk cache) part 0..4 (receive, receive + IC, preamble-equalised receive, modulate, estimator) of
  * the row-lane kernels for a shape through hiprtc WITHOUT loading it --
  * needs no GPU, so the CPU-side tests can check that the embedded kernel sources build. */

@@ -10,7 +10,7 @@ run() {   # tag path B reps slots K M L
 }
 for round in 1 2; do
   for v in mx valu; do
-    if [ $v = valu ]; then export GFDM_NO_MX=1; else unset GFDM_NO_MX; fi
+    if [ $v = valu ]; then export GFDM_MX=0; else export GFDM_MX=2; fi
     run $v demod_mf_ic2 4096 400 36 64 9 2
     run $v demod_zf_ic2 4096 400 36 64 9 2
     run $v demod_mf_ic2 65536 40 3 64 9 2

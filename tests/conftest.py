@@ -23,6 +23,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _jit_inside_the_constructor():
+    """Run-time instantiated shapes compile inside the constructor during the tests (the library's default moves long compiles to a
+    background thread, which would make the kernel family a test runs on depend on timing); the background modes have their own test."""
+    try:
+        import gfdm_amd
+        prev = gfdm_amd.set_jit(gfdm_amd.JIT_IN_CONSTRUCTOR)
+    except Exception:
+        yield
+        return
+    yield
+    gfdm_amd.set_jit(prev)
+
+
 def golden_names():
     """kernel-path fixtures (make_golden.py); the composite-transmitter fixtures (make_golden_tx.py) are tx_*"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))

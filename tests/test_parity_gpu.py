@@ -469,9 +469,10 @@ def test_ic_rounds_on_the_matrix_cores_match_the_vector_alu(M, K, L, alpha):
         feq = np.fft.fft(np.array([1, .5, .1j, .1 + .05j]), N)[None, :] * np.exp(0.01j * np.arange(B))[:, None]
         xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
         for ic_iter in (1, 2, 5):
-            mx = gfdm_amd.AdvancedReceiver(M, K, L, taps, sm, ic_iter, R.qpsk_points())
-            prev = gfdm_amd.set_ic_matrix_cores(False)
+            prev = gfdm_amd.set_ic_matrix_cores(2)         # matrix cores wherever the form applies (the default: subcarriers >= 128)
             try:
+                mx = gfdm_amd.AdvancedReceiver(M, K, L, taps, sm, ic_iter, R.qpsk_points())
+                gfdm_amd.set_ic_matrix_cores(0)
                 va = gfdm_amd.AdvancedReceiver(M, K, L, taps, sm, ic_iter, R.qpsk_points())
             finally:
                 gfdm_amd.set_ic_matrix_cores(prev)
@@ -484,7 +485,11 @@ def test_ic_rounds_on_the_matrix_cores_match_the_vector_alu(M, K, L, alpha):
                 assert rel_err(a[keep], ref[keep]) < TOL and rel_err(b[keep], ref[keep]) < TOL
                 assert rel_err(a[keep], b[keep]) < 2e-6
     # frames in, demapped symbols out (the store stage reads the rows back from the tile)
-    mx = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, 2, R.qpsk_points())
+    prev = gfdm_amd.set_ic_matrix_cores(2)
+    try:
+        mx = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, 2, R.qpsk_points())
+    finally:
+        gfdm_amd.set_ic_matrix_cores(prev)
     for per_timeslot in (True, False):
         mx.configure_frames(N + 7, 5, smap, per_timeslot)
         frames = np.concatenate((x[:, -5:], x, x[:, :2]), axis=1)
@@ -516,18 +521,73 @@ def test_phase_compensation_removes_a_common_phase():
             assert abs(np.angle(np.sum(act(nopc.demodulate(xr)) * np.conj(act(nopc.demodulate(x))))) - phi0) < 0.01
 
 
+def test_sharded_batch_on_the_gpu():
+    """The batched-blocks multi-GPU mode through its two product entry points on the ONE GPU of the test box (each device ordinal may
+    be listed several times: one handle + one stream per entry): gfdm_amd.sharding.ShardedBatch (what bench.py runs, one process per
+    GPU there) and the C++ template gr::gfdm::sharded_batch<Kernel> (one host thread per shard).  The shards together must reproduce
+    the single-handle result bit for bit -- blocks are independent, no payload is exchanged."""
+    import torch
+    import gfdm_amd
+    import gfdm_python  # noqa: F401
+    import gfdm_testing as T
+    from gfdm_amd import sharding, synth
+    M, K, L = 9, 64, 2
+    N, total = M * K, 1001
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    dev = torch.device("cuda:0")
+    sym = synth.qpsk_symbols(0, total, N, dev)
+    feq = synth.channel_response(0, total, N, dev)
+    mod = gfdm_amd.Modulator(M, K, L, taps)
+    xe = synth.through_channel(mod.modulate(sym), feq)
+    whole = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points()).demodulate_equalize(xe, feq)
+    torch.cuda.synchronize()
+    # (a) Python: three shards on device 0, device-resident shard tensors, launches prepared once and replayed
+    sb = sharding.ShardedBatch(lambda d: gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points(), device=d), [0, 0, 0])
+    plan = sb.plan(total)
+    assert [n for _, _, n in plan] == [334, 334, 333] and sb.local_blocks(total) == total
+    ins = [(xe[s:s + n].contiguous(), feq[s:s + n].contiguous()) for _, s, n in plan]
+    outs = [torch.empty(n, N, dtype=torch.complex64, device=dev) for _, _, n in plan]
+    go = sb.prepare(gfdm_amd.lib().gfdm_hip_advanced_receiver_work_device, outs, ins, [n for _, _, n in plan])
+    go()
+    sb.synchronize()
+    assert torch.equal(torch.cat(outs), whole)
+    res = sb.run("demodulate_equalize", total, ins)
+    sb.synchronize()
+    assert torch.equal(torch.cat(res), whole)
+    parts = sb.run_global("demodulate_equalize", [xe.cpu().numpy(), feq.cpu().numpy()], [N, N])
+    assert [(s, n) for s, n, _ in parts] == [(s, n) for _, s, n in plan]
+    assert np.array_equal(np.concatenate([p for _, _, p in parts]), whole.cpu().numpy())
+    # (b) C++: gr::gfdm::sharded_batch over host batches, through the test-only module
+    x_h, feq_h, sym_h = xe.cpu().numpy(), feq.cpu().numpy(), sym.cpu().numpy()
+    got = T.sharded_advanced_receive(M, K, L, list(taps.astype(np.complex64)), list(range(K)), 2, [0, 0, 0, 0], x_h, feq_h)
+    assert np.array_equal(got.reshape(total, N), whole.cpu().numpy())
+    frames, shards = T.sharded_modulate(M, K, L, list(taps.astype(np.complex64)), [0, 0], sym_h)
+    assert shards == [(0, 501), (501, 500)]
+    assert np.array_equal(frames.reshape(total, N), mod.modulate(sym).cpu().numpy())
+    assert T.shard_range(total, 2, 3) == sharding.shard_range(total, 2, 3) and T.default_device_is_per_thread()
+    with pytest.raises(RuntimeError):
+        T.sharded_modulate(M, K, L, list(taps.astype(np.complex64)), [0, 99], sym_h)          # no such device
+
+
 def test_all_zero_and_tie_inputs_follow_the_reference_decision_rule():
     """decision_maker is '> 0': an exactly-zero component maps to the NEGATIVE point."""
     import gfdm_amd
-    M, K, L = 9, 64, 2
-    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
-    nt = R.normalize_taps(taps, M)
-    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
-    x = np.zeros((2, M * K), np.complex64)
-    ref = R.advanced_receive(x, nt, M, K, L, np.arange(K), R.qpsk_points(), 2, kind="qpsk")
-    got = adv.demodulate(x)
-    assert np.abs(ref).max() > 0.01            # the all-negative decisions leave a non-zero cancellation term
-    assert rel_err(got, ref) < TOL
+    # vector-ALU rounds (compare + select) and matrix-core rounds (v_med3_f32 on x * inf: NaN for +-0 selects the negative point)
+    for (M, K, L, mode) in ((9, 64, 2, 0), (9, 64, 2, 2), (15, 128, 4, 1), (15, 128, 4, 0), (5, 32, 2, 2)):
+        prev = gfdm_amd.set_ic_matrix_cores(mode)
+        try:
+            taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+            nt = R.normalize_taps(taps, M)
+            adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+        finally:
+            gfdm_amd.set_ic_matrix_cores(prev)
+        x = np.zeros((3, M * K), np.complex64)
+        x[1] = -0.0 - 0.0j                        # negative zeros as well
+        x[2, ::7] = 1e-42                         # ... and a few subnormal samples
+        ref = R.advanced_receive(x[:2], nt, M, K, L, np.arange(K), R.qpsk_points(), 2, kind="qpsk")
+        got = adv.demodulate(x)
+        assert np.abs(ref).max() > 5e-4            # the all-negative decisions leave a non-zero cancellation term
+        assert rel_err(got[:2], ref) < TOL and np.all(np.isfinite(got))
 
 
 def test_device_entry_points_are_graph_capturable():
@@ -618,11 +678,11 @@ def test_row_lane_kernels_instantiated_at_run_time(M, K, L, alpha, tmp_path, mon
     assert (mod.kernel_name(), dem.kernel_name(), adv.kernel_name()) == ("rowlane_jit",) * 3
     if (M, K, L) == (10, 96, 2):          # (a shape no other test of this process has loaded) every handle compiles only its own kernels
         assert (n_mod, n_dem, built()) == (1, 2, 3)
-    prev = gfdm_amd.set_jit(False)
+    prev = gfdm_amd.set_jit(gfdm_amd.JIT_OFF)
     try:
-        assert prev is True and gfdm_amd.Demodulator(M, K, L, taps).kernel_name() == "generic_lds"
+        assert prev == gfdm_amd.JIT_IN_CONSTRUCTOR and gfdm_amd.Demodulator(M, K, L, taps).kernel_name() == "generic_lds"
     finally:
-        gfdm_amd.set_jit(True)
+        gfdm_amd.set_jit(prev)
     d = np.zeros((B, K, M), complex)
     d[:, smap, :] = qpsk(rng, (B, len(smap), M))
     d = d.reshape(B, N)
@@ -645,6 +705,59 @@ def test_row_lane_kernels_instantiated_at_run_time(M, K, L, alpha, tmp_path, mon
     frames = rng.standard_normal((B, N + 12)) + 1j * rng.standard_normal((B, N + 12))
     frames[:, 5:5 + N] = xe
     assert rel_err(dem.demodulate_frames(frames, feq), R.demap_from_resources(R.demodulate(xe, nt, M, K, L, feq), M, K, smap, True)) < TOL
+
+
+def test_run_time_instantiation_off_the_constructors_critical_path(tmp_path, monkeypatch):
+    """gfdm_hip_set_jit modes 2 / 3 and gfdm_hip_precompile (include/gfdm_hip.h): with a cold cache a handle for a many-timeslot shape
+    comes back at once on the generic family, gives the right answer there, and switches to the tuned kernels once the background
+    build is done; after that (code objects cached) the constructor takes the tuned kernels directly; a precompiled shape starts on
+    them even in its first process."""
+    import time
+    import gfdm_amd
+    monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(tmp_path))
+    M, K, L = 19, 32, 2
+    taps = get_frequency_domain_filter("rrc", 0.3, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((5, M * K)) + 1j * rng.standard_normal((5, M * K))
+    ref = R.demodulate(x, nt, M, K, L)
+    prev = gfdm_amd.set_jit(gfdm_amd.JIT_AUTO)
+    try:
+        t0 = time.perf_counter()
+        dem = gfdm_amd.Demodulator(M, K, L, taps)                       # 19 timeslots, nothing cached: background build
+        t_create = time.perf_counter() - t0
+        assert t_create < 1.0 and dem.kernel_name() == "generic_lds"
+        assert rel_err(dem.demodulate(x), ref) < TOL                    # served by the generic family meanwhile
+        deadline = time.perf_counter() + 300
+        while dem.kernel_name() != "rowlane_jit" and time.perf_counter() < deadline:
+            time.sleep(0.25)
+        assert dem.kernel_name() == "rowlane_jit"
+        assert rel_err(dem.demodulate(x), ref) < TOL                    # ... and by the tuned kernels afterwards
+        t0 = time.perf_counter()
+        dem2 = gfdm_amd.Demodulator(M, K, L, taps)                      # cached now: tuned kernels straight away
+        assert dem2.kernel_name() == "rowlane_jit" and time.perf_counter() - t0 < 2.0
+        # a quick shape (timeslots <= 16) is compiled inside the constructor under JIT_AUTO
+        assert gfdm_amd.Demodulator(6, 32, 2, get_frequency_domain_filter("rrc", 0.3, 6, 32, 2)).kernel_name() == "rowlane_jit"
+        # precompile: the deployment step -- afterwards the first handle of the shape starts on the tuned kernels
+        M2 = 18
+        gfdm_amd.precompile(M2, K, L, 1 | 8)                            # receive + modulate parts
+        taps2 = get_frequency_domain_filter("rrc", 0.3, M2, K, L)
+        t0 = time.perf_counter()
+        d3, m3 = gfdm_amd.Demodulator(M2, K, L, taps2), gfdm_amd.Modulator(M2, K, L, taps2)
+        assert (d3.kernel_name(), m3.kernel_name()) == ("rowlane_jit", "rowlane_jit") and time.perf_counter() - t0 < 2.0
+        gfdm_amd.precompile(9, 64, 2)                                   # compiled into the library: nothing to do, no error
+        with pytest.raises(gfdm_amd.GfdmHipError):
+            gfdm_amd.precompile(127, 16, 2)                             # generic family only
+        # JIT_BACKGROUND for any shape, also a quick one
+        gfdm_amd.set_jit(gfdm_amd.JIT_BACKGROUND)
+        mod = gfdm_amd.Modulator(7, 8, 2, get_frequency_domain_filter("rrc", 0.3, 7, 8, 2))
+        assert mod.kernel_name() in ("generic_lds", "rowlane_jit")
+        deadline = time.perf_counter() + 120
+        while mod.kernel_name() != "rowlane_jit" and time.perf_counter() < deadline:
+            time.sleep(0.1)
+        assert mod.kernel_name() == "rowlane_jit"
+    finally:
+        gfdm_amd.set_jit(prev)
 
 
 def test_handles_on_concurrent_host_threads():

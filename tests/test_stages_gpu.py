@@ -171,6 +171,14 @@ def test_stage_argument_errors():
         gfdm_amd.CyclicPrefixer(8, 4, 2, 2, np.ones(5))
     with pytest.raises(ValueError, match="cyclic shift"):
         gfdm_amd.CyclicPrefixer(8, 4, 2, 2, np.ones(4), 3)
+    # a suffix longer than the block: the reference's memcpy of in[0, cs - shift) reads past its input there (and so would a kernel)
+    with pytest.raises(ValueError, match="cs_len - shift"):
+        gfdm_amd.CyclicPrefixer(8, 0, 12, 0, np.zeros(0), 3)
+    ok = gfdm_amd.CyclicPrefixer(8, 0, 12, 0, np.zeros(0), 4)               # cs - shift == block: the whole block repeats once
+    assert np.array_equal(ok.add_cyclic_prefix(np.arange(8, dtype=np.complex64)),
+                          R.add_cyclic_prefix(np.arange(8), 0, 12, 0, np.zeros(0), 4).astype(np.complex64))
+    with pytest.raises(ValueError, match="cs_len - shift"):
+        ok.add_cyclic_prefix(np.zeros(8, np.complex64), cyclic_shift=3)
     pc = gfdm_python.Cyclic_prefixer(8, 4, 2, 2, [1, 1, 1, 1])
     with pytest.raises(RuntimeError, match=r"Input vector size\(9\) MUST be equal to Cyclic_prefix.block_size\(8\)!"):
         pc.add_cyclic_prefix(np.zeros(9, np.complex64))
@@ -186,7 +194,7 @@ def test_reference_mapper_test_shape_through_the_block_body(per_ts):
     frames through the block -- here through the batched general_work body and the scheduler stand-in, expectation from the oracle
     (pinned to pygfdm's map_to_waveform_resources in tests/test_oracle.py)."""
     import gfdm_python
-    T = gfdm_python._testing
+    import gfdm_testing as T
     M, K, A, frames = 205, 128, 110, 3
     smap = np.arange(A) + (K - A) // 2
     rng = np.random.default_rng(12)

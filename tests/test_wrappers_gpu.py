@@ -1,5 +1,5 @@
 """SURVEY.md section 8(f) row 4 -- the GNU Radio wrappers' work() bodies with ONE batched launch per scheduler call
-(gr-gfdm_amd/cpp/include/gfdm/batched_work.h), driven by a scheduler stand-in (gfdm_python._testing) that calls them the way
+(gr-gfdm_amd/cpp/include/gfdm/batched_work.h), driven by a scheduler stand-in (the test-only module gfdm_testing) that calls them the way
 GNU Radio calls work(): successive, ragged runs of noutput_items, pointers advanced by what work() returned.  Checked against the
 oracle on the whole stream and against the item accounting of the reference loops:
     lib/simple_modulator_cc_impl.cc:62-80, lib/simple_receiver_cc_impl.cc:61-77   process floor(n / block_size) blocks, return n
@@ -34,7 +34,7 @@ def qpsk(rng, shape):
 @pytest.mark.parametrize("M,K,L,alpha", [(9, 64, 2, 0.2), (5, 32, 2, 0.5), (21, 12, 2, 0.35)])
 def test_sync_block_work_bodies_with_ragged_scheduler_calls(M, K, L, alpha):
     import gfdm_python
-    T = gfdm_python._testing
+    import gfdm_testing as T
     rng = np.random.default_rng(M * K)
     bs = M * K
     taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
@@ -61,7 +61,7 @@ def test_sync_block_work_bodies_with_ragged_scheduler_calls(M, K, L, alpha):
 @pytest.mark.parametrize("with_eq", [False, True])
 def test_advanced_receiver_work_body(with_eq):
     import gfdm_python
-    T = gfdm_python._testing
+    import gfdm_testing as T
     M, K, L = 9, 64, 2
     rng = np.random.default_rng(5)
     bs = M * K
@@ -86,7 +86,7 @@ def test_advanced_receiver_work_body(with_eq):
 
 def test_transmitter_general_work_body():
     import gfdm_python
-    T = gfdm_python._testing
+    import gfdm_testing as T
     g = load_tx_golden("tx_ref_k64_m9_cdd")
     tx = gfdm_python.Transmitter(g["M"], g["K"], g["A"], g["cp"], g["cs"], g["ramp"], g["smap"].tolist(), g["per_timeslot"], g["L"], g["taps"], g["window"],
                                  [int(s) for s in g["shifts"]], [p for p in g["preambles"]])
@@ -107,7 +107,7 @@ def test_transmitter_general_work_body():
 
 def test_mapper_demapper_and_prefixer_general_work_bodies():
     import gfdm_python
-    T = gfdm_python._testing
+    import gfdm_testing as T
     g = load_tx_golden("tx_ref_k64_m9_cdd")
     M, K, A = g["M"], g["K"], g["A"]
     rng = np.random.default_rng(4)
@@ -136,7 +136,7 @@ def test_mapper_demapper_and_prefixer_general_work_bodies():
 
 def test_channel_estimator_general_work_body():
     import gfdm_python
-    T = gfdm_python._testing
+    import gfdm_testing as T
     g = load_est_golden("est_cfg2_m9_k64_a52")
     M, K, A = g["M"], g["K"], g["A"]
     est = gfdm_python.Preamble_channel_estimator(M, K, A, True, 1, g["preamble"])
@@ -156,7 +156,7 @@ def test_channel_estimator_general_work_body():
 
 def test_legacy_2d_receiver_api_and_signal_energy():
     import gfdm_python
-    T = gfdm_python._testing
+    import gfdm_testing as T
     M, K, L = 5, 32, 2                                                # shape of qa_python_bindings.py:388-415
     rng = np.random.default_rng(1)
     taps = get_frequency_domain_filter("rrc", 0.35, M, K, L)
