@@ -452,8 +452,9 @@ def main():
         return fr, eq
 
     rx_fn, sb_rx = ((L_.gfdm_hip_advanced_receiver_work_device, sb_adv) if ic_iter else (L_.gfdm_hip_receiver_demodulate_device, sb_dem))
-    # kernel name as rocprofv3 prints it; last argument = IcKind (2: cancellation rounds on the matrix cores, the form QPSK + RRC taps take)
-    rx_template = "k_row_receive<%d, %d, %d, %d, %d, %d>" % (K, M, L, 2 if ic_iter else 1, 1 if use_eq else 0, 2 if ic_iter else 0)
+    # kernel name as rocprofv3 prints it; last argument = IcKind
+    ick = 0 if not ic_iter else (2 if (K >= 128 and 4 <= M <= 16) else 1)     # 1: real even IC kernel on the vector ALU, 2: on the matrix cores (K >= 128)
+    rx_template = "k_row_receive<%d, %d, %d, %d, %d, %d>" % (K, M, L, 2 if ic_iter else 1, 1 if use_eq else 0, ick)
     mod_template = "k_row_modulate<%d, %d, %d, 0>" % (K, M, L)
 
     # ---- headline ----------------------------------------------------------------------------------------------------

@@ -80,25 +80,17 @@ __device__ __forceinline__ cf scale(cf a, float s) { return mk(a.x * s, a.y * s)
 // the non-temporal hint (`nt`).  Measured on MI355X (K=64 M=9, rocprofv3 kernel time): with plain stores the written lines sit
 // dirty in L2 and drain at the END of the kernel -- a 4096-block launch (18.9 MB written) took 12.2 us, with nt stores 10.9 us
 // (modulate 12.2 -> 10.9, ZF + 2 IC 17.0 -> 15.2); nt loads add 2-4 % at 65 536 blocks.  Explicit scope bits (sc0 / sc1 through
-// a raw buffer store) measured no better than nt alone.  A/B switches of the measurement builds: -DGFDM_NO_NT_LOAD / _STORE.
+// a raw buffer store) measured no better than nt alone.
 typedef float v2f_io __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cf ld_stream(const cf* p)
 {
-#ifndef GFDM_NO_NT_LOAD
     const v2f_io v = __builtin_nontemporal_load(reinterpret_cast<const v2f_io*>(p));
     return mk(v.x, v.y);
-#else
-    return *p;
-#endif
 }
 // base: buffer pointer, idx: element index of this lane
 __device__ __forceinline__ void st_stream(cf* base, int64_t idx, cf v)
 {
-#ifndef GFDM_NO_NT_STORE
     __builtin_nontemporal_store(v2f_io{ v.x, v.y }, reinterpret_cast<v2f_io*>(base + idx));
-#else
-    base[idx] = v;
-#endif
 }
 
 template <bool INV> __device__ __forceinline__ cf mul_mj(cf a) { return INV ? mk(-a.y, a.x) : mk(a.y, -a.x); }     // * (-j) forward, * (+j) inverse

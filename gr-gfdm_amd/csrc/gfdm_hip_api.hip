@@ -159,6 +159,11 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     const float scale = (float)(1.0 / std::sqrt(std::fabs(energy) / M));
     pl.h_taps.resize(ntaps);
     for (int i = 0; i < ntaps; ++i) pl.h_taps[i] = make_float2(taps[2 * i] * scale, taps[2 * i + 1] * scale);
+    // real taps (imaginary parts below anything float32 arithmetic can see next to the real parts: an RRC response computed in double
+    // carries ~1e-17): the kernels then take two multiply-adds per tap product instead of four.  filter_taps() keeps returning h_taps.
+    float tmax = 0.f, imax = 0.f;
+    for (const cf& t : pl.h_taps) { tmax = std::fmax(tmax, std::fmax(std::fabs(t.x), std::fabs(t.y))); imax = std::fmax(imax, std::fabs(t.y)); }
+    const bool taps_real = imax <= 1e-12f * tmax;
     pl.h_ictaps.assign(M, make_float2(0.f, 0.f));
     if (L >= 2)                                                    // lib/receiver_kernel_cc.cc:56-63
         for (int m = 0; m < M; ++m) {
@@ -168,7 +173,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
 
     std::vector<cf> tables;
     tables.reserve((size_t)ntaps + 4 * M + K + 2 * (size_t)N);
-    tables.insert(tables.end(), pl.h_taps.begin(), pl.h_taps.end());
+    for (const cf& t : pl.h_taps) tables.push_back(taps_real ? make_float2(t.x, 0.f) : t);
     tables.insert(tables.end(), pl.h_ictaps.begin(), pl.h_ictaps.end());
     for (int m = 0; m < M; ++m) tables.push_back(make_float2(pl.h_ictaps[m].x / (float)M, pl.h_ictaps[m].y / (float)M));
     // g = IDFT_M(ic)/M in double: one IC round is d_new = d0 - g (*) (dec_{k-1} + dec_{k+1})  (gfdm_rowlane_impl.h)
@@ -209,7 +214,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
 
     // Matrix-core form of the cancellation rounds (IcMfma, gfdm_rowlane_impl.h): the A operand of v_mfma_f32_16x16x32_f16, lane l holds
     // A[row l & 15][k = 8 (l >> 4) + j], j < 8.  Row p = output timeslot; k < 16: high f16 term of a[p][r = k], k >= 16: the residual term of
-    // r = k - 16, with a[p][r] = -s g[(p - r) mod M] 2^e (s = 1/sqrt 2: the QPSK amplitude; e puts the largest entry near 2^8 so that the
+    // r = k - 16 (a second operand holds the next residual term), with a[p][r] = -s g[(p - r) mod M] 2^e (s = 1/sqrt 2: the QPSK amplitude; e puts the largest entry near 2^8 so that the
     // residual terms stay normal f16 numbers).  The decisions enter as +-2^-e, exact in f16.
     size_t icA_off = 0;                     // (behind every other table: the pointers below are offsets into `tables`)
     unsigned ic_sig = 0;
@@ -224,20 +229,23 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
         const double c = std::ldexp(1.0, e);
         if (tables.size() & 1) tables.push_back(make_float2(0.f, 0.f));        // 16-byte alignment of the operand table
         icA_off = tables.size();
-        for (int lane = 0; lane < 64; ++lane) {
-            _Float16 h[8];
-            for (int j = 0; j < 8; ++j) {
-                const int pr = lane & 15, k = 8 * (lane >> 4) + j, r = k & 15;
-                double a = 0.0;
-                if (pr < M && r < M) a = -s * (double)g_real[((pr - r) % M + M) % M] * c;
-                const _Float16 hi = (_Float16)a;
-                h[j] = (k < 16) ? hi : (_Float16)(a - (double)hi);
+        for (int op = 0; op < 2; ++op)                             // operand 0: [high | residual], operand 1: [second residual | 0]
+            for (int lane = 0; lane < 64; ++lane) {
+                _Float16 h[8];
+                for (int j = 0; j < 8; ++j) {
+                    const int pr = lane & 15, k = 8 * (lane >> 4) + j, r = k & 15;
+                    double a = 0.0;
+                    if (pr < M && r < M) a = -s * (double)g_real[((pr - r) % M + M) % M] * c;
+                    const _Float16 hi = (_Float16)a;
+                    const _Float16 mid = (_Float16)(a - (double)hi);
+                    const _Float16 lo = (_Float16)(a - (double)hi - (double)mid);
+                    h[j] = (op == 0) ? ((k < 16) ? hi : mid) : ((k < 16) ? lo : (_Float16)0.0);
+                }
+                cf packed[2];
+                static_assert(sizeof packed == sizeof h, "8 f16 = 2 complex floats");
+                memcpy(packed, h, sizeof packed);
+                tables.insert(tables.end(), packed, packed + 2);
             }
-            cf packed[2];
-            static_assert(sizeof packed == sizeof h, "8 f16 = 2 complex floats");
-            memcpy(packed, h, sizeof packed);
-            tables.insert(tables.end(), packed, packed + 2);
-        }
         const _Float16 sig = (_Float16)std::ldexp(1.0, -e);
         unsigned short bits;
         memcpy(&bits, &sig, sizeof bits);
@@ -255,6 +263,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     dp.log2K = ilog2_exact(K);
     dp.part_len = (M * L / 2 < M) ? (M * L / 2) : M;
     dp.taps = pl.d_tables;
+    dp.taps_real = taps_real ? 1 : 0;
     dp.ictaps = dp.taps + ntaps;
     dp.ictaps_m = dp.ictaps + M;
     dp.icg = dp.ictaps_m + M;

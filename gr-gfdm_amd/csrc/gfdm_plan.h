@@ -21,12 +21,13 @@ struct DevicePlan {
     int log2K;      // >= 0 when K is a power of two, else -1
     int part_len;   // min(M*L/2, M): bins of each tap part the modulator accumulates (modulator_kernel_cc.cc:101)
     const cf* taps;     // [L*M] normalised filter taps
+    int taps_real;      // 1 when every tap is real (RRC / RC and every other real, even prototype filter): two multiply-adds per tap product
     const cf* ictaps;   // [M]   ic[m] = t[m] * t[(L-1)M + m]
     const cf* ictaps_m; // [M]   ic[m] / M (IC taps with the inverse-DFT scale folded in)
     const cf* icg;      // [M]   g = IDFT_M(ic) / M: circular-convolution form of one cancellation round
     int ic_real_sym;    // 1 when g is real and even (real, even prototype filter): only g[0..M/2].x is used
     // matrix-core form of a cancellation round (gfdm_rowlane_impl.h, ICK_MFMA; QPSK decisions, g real, M <= 16):
-    const void* icA;    // [64 lanes][8 f16] A operand of v_mfma_f32_16x16x32_f16: the circulant -s g[(p - r) mod M] 2^e, split in two f16
+    const void* icA;    // [2][64 lanes][8 f16] A operands of v_mfma_f32_16x16x32_f16: the circulant -s g[(p - r) mod M] 2^e as three f16 terms
     unsigned ic_sig;    // f16 bits of 2^-e: magnitude of one QPSK decision in the B operand (0: no table, vector-ALU rounds only)
     const cf* wM;       // [M]   exp(-2 pi j p / M)
     const cf* wK;       // [K]   exp(-2 pi j q / K)

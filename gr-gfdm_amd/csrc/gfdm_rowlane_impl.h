@@ -86,17 +86,9 @@ template <int K> struct RowShape {
     // K = 256 = 16 x 16: TWO radix-16 passes instead of four radix-4 passes (lds_subcarrier_fft16): half the LDS traffic and half
     // the ordering points of the subcarrier FFT, the same butterfly arithmetic.  This shape is LDS-limited to two blocks per CU,
     // so its launch time is close to the SUM of its HBM, LDS and VALU time rather than their maximum.
-#ifndef GFDM_NO_RADIX16
     static constexpr bool RADIX16 = (K == 256);
-#else
-    static constexpr bool RADIX16 = false;
-#endif
     // K = 128 = 8 x 16: one radix-8 and one radix-16 pass instead of three radix-4 passes and a radix-2 pass (lds_subcarrier_fft8x16)
-#ifndef GFDM_NO_RADIX8X16
     static constexpr bool RADIX8X16 = (K == 128);
-#else
-    static constexpr bool RADIX8X16 = false;
-#endif
     // K = 512 = 8 x 8 x 8, K = 1024 = 8 x 8 x 16: THREE wide passes (lds_subcarrier_fft3) instead of four or five radix-4 / radix-2 passes
     static constexpr bool WIDE3 = (K == 512 || K == 1024) || MIXED3;
     static constexpr bool WIDE = RADIX16 || RADIX8X16 || MIXED || WIDE3;   // FftTwiddles holds the twiddles of the wide passes
@@ -352,7 +344,6 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
         lds_subcarrier_fft2<K, M, INV, S::WIDE_R0, S::WIDE_R1>(tile, lane, twd);
         return;
     }
-#ifndef GFDM_NO_R16_TAIL
     if constexpr (K == 64 && FIRST == 1) {
         // K = 64 behind the register first pass: the remaining 16-point transforms (rows tq + 4 r) as ONE radix-16 pass instead of
         // two radix-4 passes.  Lane (tq, cg) = (lane % 4, lane / 4) reads and writes its own rows; the same butterfly instructions
@@ -375,7 +366,6 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
         block_sync<K>();
         return;
     }
-#endif
     constexpr int RG = S::RG, CMAX = (M + 3) / 4;
     const int tq = lane % RG, cg = lane / RG, c0 = cg * CMAX;
     const cf* rb[4];
@@ -438,11 +428,7 @@ __device__ __forceinline__ void lds_subcarrier_fft(cf* tile, int lane, const Fft
 // lane rows (v_permlane32_swap + v_permlane16_swap, two of each per 32-bit component) hands lane (rr, tq) the four inputs of
 // the butterfly of column 4 c + rr: the pass needs neither the row store to the tile nor the 12 LDS reads nor the ordering
 // point between them, and all 64 lanes work (the LDS form leaves the lanes of the fourth column group idle).
-#ifndef GFDM_NO_REG_FIRST_PASS
 constexpr bool kRegFirstPass = true;
-#else
-constexpr bool kRegFirstPass = false;
-#endif
 
 // register i of lane row rr  <-  register rr of lane row i.  v_permlane32_swap(a, b): rows 2,3 of a <-> rows 0,1 of b;
 // v_permlane16_swap(a, b): rows 1,3 of a <-> rows 0,2 of b (checked on hardware, scratch/probe/permlane.hip).
@@ -493,6 +479,14 @@ __device__ __forceinline__ float dpp_wave_rol1(float x)
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x134, 0xF, 0xF, false));
 }
 
+// c + t x for a filter tap t: prototype filters such as RRC / RC have REAL frequency-domain taps (DevicePlan::taps_real, decided once per
+// handle), and then the product is two multiply-adds instead of four -- the branch is uniform for the whole launch
+template <bool TREAL>
+__device__ __forceinline__ cf tap_fma(cf t, cf x, cf c)
+{
+    if constexpr (TREAL) return mk(fmaf(t.x, x.x, c.x), fmaf(t.x, x.y, c.y)); else return cfma(t, x, c);
+}
+
 __device__ __forceinline__ cf decide_point(cf x, const IcParams& ic)
 {
     if (ic.decision == 1) {
@@ -518,13 +512,14 @@ __device__ __forceinline__ cf decide_point(cf x, const IcParams& ic)
 // One round is  d_new[k][p] = d0[k][p] - sum_r g[(p - r) mod M] (dec[k-1][r] + dec[k+1][r]):  per block a product of the M x M circulant
 // of g with an M x 2K matrix of decisions -- the one dense contraction of the receiver.  With QPSK decisions that matrix holds only
 // 0, +-s, +-2s: EXACT in f16.  So the product runs as  D = A B + C  on v_mfma_f32_16x16x32_f16 with
-//   A (16 x 32, per-handle table p.icA) = [ hi | mid ], the two-term f16 split of  -s g[(p - r) mod M] 2^e  (22 significant bits; the
-//     32-deep contraction holds both terms against the same 16 decision rows),
+//   A (16 x 32, per-handle table p.icA) = [ hi | mid ] and [ lo | 0 ], the three-term f16 split of  -s g[(p - r) mod M] 2^e  (33 significant
+//     bits, more than the 24 of the f32 taps themselves: the g[r] largely cancel in the sum, so a two-term split showed 4e-5 relative error
+//     on the degenerate all-zero input; the 32-deep contraction holds two terms against the same 16 decision rows),
 //   B (32 x 16) = the decisions of 16 subcarriers and one component, sigma[k-1] + sigma[k+1] in units of 2^-e, both 8-row halves twice,
 //   C = d0, D = d_new in f32 (products of f16 values are exact in the f32 accumulator),
-// 8 MFMAs per wavefront (4 groups of 16 subcarriers x re / im) and round in place of M(M+1)/2 packed multiply-adds, M(M-1)/2 packed
+// 16 MFMAs per wavefront (4 groups of 16 subcarriers x re / im x two A operands) and round in place of M(M+1)/2 packed multiply-adds, M(M-1)/2 packed
 // adds and the neighbour moves of the vector-ALU form: at M = 15 the two rounds of BASELINE configs[3] drop from ~1100 vector issue slots
-// per wave to ~250 plus 16 MFMAs that run beside the other waves' vector work.
+// per wave to ~250 plus 32 MFMAs that run beside the other waves' vector work.
 // Layouts: C / D lane (cn = lane & 15, cr = lane >> 4) holds subcarrier 16 gi + cn, timeslots 4 cr .. 4 cr + 3; the B operand wants
 // timeslots 8 (cr & 1) .. + 7 of the NEIGHBOUR subcarriers, so the decisions cross LDS once per round as an f16 image
 // [component][half][K][8] in the block's own tile (written 8 bytes, read 16 bytes per lane, conflict free), d0 / the result cross it
@@ -538,16 +533,12 @@ template <int K, int M> struct IcMfma {
     static constexpr int NH = rowgeom::ic_mfma_halves(M);
     static constexpr int PS = (K + 2) * 16;                   // bytes of one [K + 2 rows][8 f16] plane: rows -1 and K are copies of K - 1 and 0
     static constexpr int IMG = (int)rowgeom::ic_mfma_image(K, M);   // one image = 2 components x NH halves
-#ifndef GFDM_IC_SINGLE_IMAGE
     static constexpr bool DB = !rowgeom::wave_local(K);       // two images: ONE workgroup barrier per round
-#else
-    static constexpr bool DB = false;
-#endif
     // group gi of a wavefront = its lanes' rows 16 gi .. 16 gi + 15: which block of the wavefront (K < 64) and which row inside it
     static constexpr int grp_block(int gi) { return K < 64 ? (16 * gi) / K : 0; }
     static constexpr int grp_row(int gi) { return K < 64 ? (16 * gi) % K : 16 * gi; }
     struct Pre {
-        uint4 a;               // A operand of this lane
+        uint4 a, a2;           // A operands of this lane: [high | residual] and [second residual | 0]
         float sig[4];          // per 16-subcarrier group: the decision magnitude 2^-e, 0 on an inactive subcarrier
     };
 
@@ -556,6 +547,7 @@ template <int K, int M> struct IcMfma {
     {
         const int lane = threadIdx.x & 63, r0 = (threadIdx.x & ~63) + (lane & 15);
         pre.a = reinterpret_cast<const uint4*>(p.icA)[lane];
+        pre.a2 = reinterpret_cast<const uint4*>(p.icA)[64 + lane];
         const float sig = (float)__builtin_bit_cast(_Float16, (unsigned short)p.ic_sig);      // 2^-e, carried as its f16 bit pattern
         static_for<0, 4>([&](auto gi) {
             constexpr int g4 = decltype(gi)::value;
@@ -583,7 +575,7 @@ template <int K, int M> struct IcMfma {
         const int wrow = threadIdx.x & ~63;                   // first row of this wavefront in the workgroup's lane space
         const int n0 = (K < 64) ? cn : ((wrow & (K - 1)) + cn);   // row of group 0's lane inside its block
         unsigned char* blk0 = smem + (size_t)(wrow / K) * TS * sizeof(cf);     // tile of the wavefront's first block
-        const ic_h8 afrag = __builtin_bit_cast(ic_h8, pre.a);
+        const ic_h8 afrag = __builtin_bit_cast(ic_h8, pre.a), afrag2 = __builtin_bit_cast(ic_h8, pre.a2);
         // d0 in the C / D layout: timeslots 4 cr .. 4 cr + 3 of subcarrier n0 + 16 gi, real and imaginary parts apart.  (Timeslots >= M
         // read whatever follows in the tile: padding rows of the 16 x 16 product, never stored.)
         ic_f4 c0[4][2], cur[4][2];
@@ -636,7 +628,9 @@ template <int K, int M> struct IcMfma {
                     const unsigned char* src = rbase + img_off + goff + c * NH * PS;
                     const ic_h8 below = *reinterpret_cast<const ic_h8*>(src);
                     const ic_h8 above = *reinterpret_cast<const ic_h8*>(src + 32);
-                    cur[g4][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, below + above, c0[g4][c], 0, 0, 0);
+                    const ic_h8 nb = below + above;
+                    cur[g4][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag2, nb, c0[g4][c], 0, 0, 0);      // smallest terms first
+                    cur[g4][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, nb, cur[g4][c], 0, 0, 0);
                 });
             });
             if constexpr (!DB) block_sync<K>();               // all neighbour reads done before the image is rewritten
@@ -668,12 +662,7 @@ template <int K, int M> struct IcMfma {
 // VGPRs, which the dead registers of the FFT phases provide; with the default bound it takes 64 AGPRs ON TOP: 108 + 64 registers = 2 waves
 // per SIMD instead of 120 = 4)
 template <int K, int M, int L, int MODE, int EQ, int ICK>
-#ifdef GFDM_K128_WAVES      /* A/B builds: ask for more waves per SIMD (fewer registers) on the K = 128 kernels */
-#define GFDM_RX_MIN_WAVES(K_, ICMX_) ((K_) == 128 ? GFDM_K128_WAVES : (ICMX_) ? 2 : 1)
-#else
-#define GFDM_RX_MIN_WAVES(K_, ICMX_) ((ICMX_) ? 2 : 1)
-#endif
-__global__ __launch_bounds__(RowShape<K>::WG, GFDM_RX_MIN_WAVES(K, MODE == RX_IC && ICK == ICK_MFMA)) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
+__global__ __launch_bounds__(RowShape<K>::WG, (MODE == RX_IC && ICK == ICK_MFMA) ? 2 : 1) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
                                                                 cf* __restrict__ out, const cf* __restrict__ in,
                                                                 const cf* __restrict__ f_eq, int64_t nblocks)
 {
@@ -708,6 +697,7 @@ __global__ __launch_bounds__(RowShape<K>::WG, GFDM_RX_MIN_WAVES(K, MODE == RX_IC
         if constexpr (MODE == RX_IC) static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; icgv[i] = p.icg[i]; });
     }
     auto tap = [&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (PRE_TAPS) return tapv[i]; else return p.taps[i]; };
+    const bool treal = p.taps_real != 0;
     auto icg = [&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (PRE_TAPS && MODE == RX_IC) return icgv[i]; else return p.icg[i]; };
     const int wgt = (MODE == RX_IC && !ICMX) ? ic.active[q] : 0;      // multiplicity of subcarrier k in subcarrier_map (0 = inactive)
     typename IcMfma<ICMX ? K : 16, ICMX ? M : 4>::Pre icpre;
@@ -750,9 +740,7 @@ __global__ __launch_bounds__(RowShape<K>::WG, GFDM_RX_MIN_WAVES(K, MODE == RX_IC
     cf xrow[ROWREG ? M : 1];
     cf heq[EQ == EQ_VECTOR ? M : 1];
     if constexpr (EQ == EQ_VECTOR) {
-#ifndef GFDM_EAGER_FEQ
         __builtin_amdgcn_sched_barrier(0);
-#endif
         static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; heq[i] = ld_stream(f_eq + base + q + K * i); });
     }
 
@@ -819,28 +807,32 @@ __global__ __launch_bounds__(RowShape<K>::WG, GFDM_RX_MIN_WAVES(K, MODE == RX_IC
     // ---- phase D: S[k][m] = sum_i taps[((i + L/2) % L) M + m] X[(k + i - L/2) mod K][m]                      rx:165-192
     cf s[M];
     static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = mk(0.f, 0.f); });
-    if constexpr (K == 64 && L == 2) {
-        // the block IS the wavefront and the only foreign row is k - 1 = lane k - 1: a DPP wave rotate of the own row replaces the
-        // second LDS row read
-        const cf* rb = X + q * MS;
-        static_for<0, M>([&](auto mi) {
-            constexpr int m = decltype(mi)::value;
-            cf own;
-            if constexpr (ROWREG) own = xrow[m]; else own = rb[m];
-            const cf below = mk(dpp_wave_ror1(own.x), dpp_wave_ror1(own.y));
-            s[m] = cfma(tap(std::integral_constant<int, M + m>{}), below, s[m]);       // i = 0: row k - 1
-            s[m] = cfma(tap(std::integral_constant<int, m>{}), own, s[m]);             // i = 1: row k
-        });
-    } else {
-        static_for<0, L>([&](auto ii) {
-            constexpr int i = decltype(ii)::value;
-            const cf* rb = X + wrap_k<K>(q + i - L / 2 + K) * MS;
+    auto filter = [&](auto real_tag) {                     // one copy per kind of taps, chosen by a uniform branch
+        constexpr bool TREAL = decltype(real_tag)::value;
+        if constexpr (K == 64 && L == 2) {
+            // the block IS the wavefront and the only foreign row is k - 1 = lane k - 1: a DPP wave rotate of the own row replaces the
+            // second LDS row read
+            const cf* rb = X + q * MS;
             static_for<0, M>([&](auto mi) {
                 constexpr int m = decltype(mi)::value;
-                s[m] = cfma(tap(std::integral_constant<int, ((i + L / 2) % L) * M + m>{}), rb[m], s[m]);
+                cf own;
+                if constexpr (ROWREG) own = xrow[m]; else own = rb[m];
+                const cf below = mk(dpp_wave_ror1(own.x), dpp_wave_ror1(own.y));
+                s[m] = tap_fma<TREAL>(tap(std::integral_constant<int, M + m>{}), below, s[m]);       // i = 0: row k - 1
+                s[m] = tap_fma<TREAL>(tap(std::integral_constant<int, m>{}), own, s[m]);             // i = 1: row k
             });
-        });
-    }
+        } else {
+            static_for<0, L>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const cf* rb = X + wrap_k<K>(q + i - L / 2 + K) * MS;
+                static_for<0, M>([&](auto mi) {
+                    constexpr int m = decltype(mi)::value;
+                    s[m] = tap_fma<TREAL>(tap(std::integral_constant<int, ((i + L / 2) % L) * M + m>{}), rb[m], s[m]);
+                });
+            });
+        }
+    };
+    if (treal) filter(std::true_type{}); else filter(std::false_type{});
     constexpr float invM = 1.0f / (float)M;
     cf d[M];
     if constexpr (MODE != RX_FD) {
@@ -1012,6 +1004,7 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
     if constexpr (PRE_TW) static_for<1, M>([&](auto mi) { constexpr int m = decltype(mi)::value; twv[m] = twT[m * K + q]; });
     if constexpr (PRE_TAPS) static_for<0, L * M>([&](auto ii) { constexpr int i = decltype(ii)::value; tapv[i] = p.taps[i]; });
     auto tap = [&](auto ii) { constexpr int i = decltype(ii)::value; if constexpr (PRE_TAPS) return tapv[i]; else return p.taps[i]; };
+    const bool treal = p.taps_real != 0;
     cf v[M];
     if constexpr (TXMODE == 0) {
         // symbols [k][p], copied linearly (coalesced) into the tile; lane k then owns row k
@@ -1027,31 +1020,37 @@ __global__ __launch_bounds__(RowShape<K>::WG) void k_row_modulate(DevicePlan p, 
     dft_inplace<M, false>(v);                                                                          // mod:109-110
     // gather form of filter + overlap-add: Y[j][m] = sum_i D[(j - i + L/2) mod K][m] taps[((i + L/2) % L) M + m]   mod:116-132
     constexpr float invN = 1.0f / (float)N;
-    if constexpr (K == 64 && L == 2) {
-        // the block is the wavefront and the only foreign row is j + 1: fetch it with a DPP wave rotate, no LDS round trip
-        static_for<0, M>([&](auto mi) {
-            constexpr int m = decltype(mi)::value;
-            const cf up = mk(dpp_wave_rol1(v[m].x), dpp_wave_rol1(v[m].y));          // D[(j + 1) mod K][m]   (i = 0)
-            cf acc = mk(0.f, 0.f);
-            if constexpr (m < PART) {
-                acc = cfma(up, tap(std::integral_constant<int, M + m>{}), acc);
-                acc = cfma(v[m], tap(std::integral_constant<int, m>{}), acc);                                     // D[j][m]              (i = 1)
-            }
-            v[m] = acc;
-        });
-    } else {
+    if constexpr (!(K == 64 && L == 2)) {
         static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = v[m]; });    // own row: no hazard
         block_sync<K>();
-        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = mk(0.f, 0.f); });
-        static_for<0, L>([&](auto ii) {
-            constexpr int i = decltype(ii)::value;
-            const cf* rb = X + wrap_k<K>(q - i + L / 2 + K) * M;
-            static_for<0, PART>([&](auto mi) {
-                constexpr int m = decltype(mi)::value;
-                v[m] = cfma(rb[m], tap(std::integral_constant<int, ((i + L / 2) % L) * M + m>{}), v[m]);
-            });
-        });
     }
+    auto filter = [&](auto real_tag) {                     // one copy per kind of taps, chosen by a uniform branch
+        constexpr bool TREAL = decltype(real_tag)::value;
+        if constexpr (K == 64 && L == 2) {
+            // the block is the wavefront and the only foreign row is j + 1: fetch it with a DPP wave rotate, no LDS round trip
+            static_for<0, M>([&](auto mi) {
+                constexpr int m = decltype(mi)::value;
+                const cf up = mk(dpp_wave_rol1(v[m].x), dpp_wave_rol1(v[m].y));          // D[(j + 1) mod K][m]   (i = 0)
+                cf acc = mk(0.f, 0.f);
+                if constexpr (m < PART) {
+                    acc = tap_fma<TREAL>(tap(std::integral_constant<int, M + m>{}), up, acc);
+                    acc = tap_fma<TREAL>(tap(std::integral_constant<int, m>{}), v[m], acc);                                     // D[j][m]              (i = 1)
+                }
+                v[m] = acc;
+            });
+        } else {
+            static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = mk(0.f, 0.f); });
+            static_for<0, L>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const cf* rb = X + wrap_k<K>(q - i + L / 2 + K) * M;
+                static_for<0, PART>([&](auto mi) {
+                    constexpr int m = decltype(mi)::value;
+                    v[m] = tap_fma<TREAL>(tap(std::integral_constant<int, ((i + L / 2) % L) * M + m>{}), rb[m], v[m]);
+                });
+            });
+        }
+    };
+    if (treal) filter(std::true_type{}); else filter(std::false_type{});
     block_sync<K>();                                      // neighbour rows read by everyone before they are overwritten
     constexpr bool REGPASS = (K == 64) && kRegFirstPass;
     static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; v[m] = scale(v[m], invN); });
@@ -1098,9 +1097,7 @@ hipError_t launch_rx(const DevicePlan& p, const IcParams& ic, const EstPlan* est
     const EstPlan& e = est ? *est : kNoEst;
     const bool pre = (PART == 2) || (PART == 4 && est);                          // EQ_PREAMBLE: two more tile columns + the estimate behind the tiles
     size_t lds = pre ? row_lds_bytes<K, M + 2>() + EstTile<K>::bytes : row_lds_bytes<K, M>();
-#ifndef GFDM_IC_SINGLE_IMAGE
     if (PART == 4 && lds < rowgeom::ic_mfma_lds(K, M)) lds = rowgeom::ic_mfma_lds(K, M);
-#endif
     if (PART == 4) lds += 128;            // the padding rows of the 16 x 16 tiles read up to 11 values past the last row
 #define GFDM_RX(MODE_, EQ_, ICK_)                                                                                                       \
     do {                                                                                                                            \

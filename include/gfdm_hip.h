@@ -87,8 +87,8 @@ int gfdm_hip_set_jit(int mode);
  * the generic family serves.  Command line: python -m gfdm_amd.precompile <timeslots> <subcarriers> <overlap> [...]. */
 int gfdm_hip_precompile(int timeslots, int subcarriers, int overlap, unsigned parts);
 /* The interference-cancellation rounds of the advanced receiver (lib/advanced_receiver_kernel_cc.cc:56-76, lib/receiver_kernel_cc.cc:274-299)
- * can run on the matrix cores (v_mfma_f32_16x16x32_f16; the QPSK decisions are exact in f16, the IC taps enter as a two-term f16 split with
- * 22 significant bits, sums in f32) where that form applies: QPSK sign decisions, a real even IC kernel (any real, even prototype filter),
+ * can run on the matrix cores (v_mfma_f32_16x16x32_f16; the QPSK decisions are exact in f16, the IC taps enter as a three-term f16 split with
+ * 33 significant bits, sums in f32) where that form applies: QPSK sign decisions, a real even IC kernel (any real, even prototype filter),
  * no phase compensation, 4 .. 16 timeslots and a power-of-two number of subcarriers >= 16 on the row-lane kernels.  Mode of the handles
  * created afterwards (returns the previous mode): 0 = vector ALU only (f32 throughout), 1 (default) = matrix cores where they are the
  * faster form (blocks of two or more wavefronts: subcarriers >= 128), 2 = matrix cores wherever the form applies. */
