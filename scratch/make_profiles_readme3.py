@@ -13,9 +13,12 @@ LABEL = {"modulate": "modulate", "demod_mf": "MF demod", "demod_zf": "ZF demod",
 R2 = {("modulate", 4096): 10.17, ("demod_mf", 4096): 9.84, ("demod_zf", 4096): 12.80, ("demod_mf_ic2", 4096): 12.06, ("demod_zf_ic2", 4096): 14.70,
       ("frames_zf_ic2_est", 4096): 15.53, ("estimate_frame", 4096): 7.56, ("modulate", 65536): 107.57, ("demod_mf", 65536): 108.02, ("demod_zf", 65536): 147.03,
       ("demod_mf_ic2", 65536): 141.39, ("demod_zf_ic2", 65536): 167.93, ("frames_zf_ic2_est", 65536): 182.73, ("estimate_frame", 65536): 69.74}
-R2S = {("128_15_4_65536", "demod_mf"): 394.4, ("128_15_4_65536", "demod_mf_ic2"): 543.7, ("128_15_4_65536", "demod_zf"): 526.8, ("128_15_4_65536", "demod_zf_ic2"): 636.3,
-       ("128_15_4_65536", "modulate"): 386.1, ("128_15_4_8192", "demod_mf"): 52.4, ("128_15_4_8192", "demod_mf_ic2"): 74.9, ("128_15_4_8192", "demod_zf"): 69.4,
-       ("128_15_4_8192", "demod_zf_ic2"): 88.6, ("128_15_4_8192", "modulate"): 54.0}
+R2S = {}
+try:
+    for _r in csv.DictReader(open(os.path.join("profiles", "r02", "shape_kernel_durations.csv"))):
+        R2S[(_r["shape_batch"], _r["path"])] = float(_r["mean_us"])
+except OSError:
+    pass
 
 
 def base_path(path):
