@@ -18,6 +18,9 @@ adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, qpsk)
 ins, eqs, outs = [], [], []
 for s in range(slots):
     sym = synth.qpsk_symbols(s * B, B, N, dev)
+    if path == "modulate":                 # no receiver inputs needed: the trace then holds nothing but the measured modulator launches
+        ins.append((sym, None, None)); eqs.append(None); outs.append(torch.empty_like(sym))
+        continue
     x = mod.modulate(sym); f = synth.channel_response(s * B, B, N, dev); xe = synth.through_channel(x, f)
     ins.append((sym, x, xe)); eqs.append(f); outs.append(torch.empty_like(x))
 if path in ("frames_zf_ic2_est", "estimate_frame"):      # channel estimator, stand-alone / fused in front of ZF + 2 IC + demapper (52 active)

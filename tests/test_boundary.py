@@ -204,6 +204,57 @@ def test_row_lane_kernels_build_through_hiprtc(tmp_path, monkeypatch):
         assert L.gfdm_hip_jit_build_for_testing(M, K, Lp, 0) != 0
 
 
+def test_precompile_and_library_switches_without_a_gpu(tmp_path, monkeypatch):
+    """gfdm_hip_precompile (the deployment step of INTEGRATION.md) fills the code-object cache without a handle or a GPU; the two
+    library switches keep their mode and clamp it; python -m gfdm_amd.precompile is the command-line form."""
+    import subprocess
+    import sys
+    import gfdm_amd
+    monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(tmp_path))
+    gfdm_amd.precompile(6, 16, 2, 1 | 8)                               # receive + modulate parts of a run-time shape
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 2
+    gfdm_amd.precompile(9, 64, 2)                                      # compiled into the library: nothing to do
+    with pytest.raises(gfdm_amd.GfdmHipError):
+        gfdm_amd.precompile(127, 16, 2)                                # generic family only
+    assert os.stat(tmp_path).st_mode & 0o022 == 0                      # (pytest's tmp_path is private already)
+    prev = gfdm_amd.set_jit(gfdm_amd.JIT_BACKGROUND)
+    try:
+        assert gfdm_amd.set_jit(99) == gfdm_amd.JIT_BACKGROUND and gfdm_amd.set_jit(gfdm_amd.JIT_OFF) == gfdm_amd.JIT_AUTO
+        assert gfdm_amd.set_jit(True) == gfdm_amd.JIT_OFF and gfdm_amd.set_jit(prev) == gfdm_amd.JIT_IN_CONSTRUCTOR
+    finally:
+        gfdm_amd.set_jit(prev)
+    mx = gfdm_amd.set_ic_matrix_cores(2)
+    try:
+        assert gfdm_amd.set_ic_matrix_cores(7) == 2 and gfdm_amd.set_ic_matrix_cores(0) == 2 and gfdm_amd.set_ic_matrix_cores(mx) == 0
+    finally:
+        gfdm_amd.set_ic_matrix_cores(mx)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "gr-gfdm_amd", "python"), GFDM_HIP_CACHE_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "gfdm_amd.precompile", "6", "16", "2", "--parts", "rx", "9", "64", "2", "127", "16", "2"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout.count("ready") == 2 and "generic kernel family" in r.stdout, r.stdout + r.stderr
+
+
+def test_a_cache_directory_others_can_write_is_not_used(tmp_path, monkeypatch):
+    """The code objects in the cache are handed to hipModuleLoadData: a directory that group / others can write (or that is a symbolic
+    link) disables the disk cache -- the shape still compiles, in memory, and nothing is written there."""
+    import gfdm_amd
+    bad = tmp_path / "shared"
+    bad.mkdir()
+    os.chmod(bad, 0o777)
+    monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(bad))
+    L = gfdm_amd.lib()
+    assert L.gfdm_hip_jit_build_for_testing(5, 16, 2, 3) == 0, L.gfdm_hip_last_error()
+    assert os.listdir(bad) == []
+    good = tmp_path / "private"
+    link = tmp_path / "link"
+    good.mkdir()
+    os.symlink(good, link)
+    monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(link))
+    assert L.gfdm_hip_jit_build_for_testing(5, 16, 2, 3) == 0 and os.listdir(good) == []
+    monkeypatch.setenv("GFDM_HIP_CACHE_DIR", str(good))
+    assert L.gfdm_hip_jit_build_for_testing(5, 16, 2, 3) == 0 and len(os.listdir(good)) == 2
+
+
 def test_gnuradio_block_wrappers_compile_against_a_mock_of_the_block_api():
     """gfdm/gr_blocks.h (complete gr::sync_block subclasses over the batched work() bodies) is compiled only where GNU Radio is
     installed, which is neither here nor on the GPU box.  Syntax-check it against tests/mock_gnuradio: a test double that declares the
