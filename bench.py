@@ -88,6 +88,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the per-variant measurements")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="wall time of each cpu_baseline leg (two or three legs)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the N > 1 run (nccl = RCCL over xGMI; gloo lets several ranks share ONE GPU, "
+                         "which is how the whole N > 1 path is exercised on a single-GPU box: every rank then uses device LOCAL_RANK %% device count)")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="no GPU, no GFDM compute: run launcher + rendezvous (gloo) + shard plan + synthetic-input checksum all-reduce "
                          "and print them (tests/test_bench_launcher.py)")
@@ -402,10 +405,15 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels have no CPU fallback")
+    if a.dist_backend == "gloo":
+        local = local % torch.cuda.device_count()                    # test mode: the ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL; only barriers / stat reductions
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL; only barriers / stat reductions
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import gfdm_amd
     from gfdm_amd import sharding, synth

@@ -28,6 +28,8 @@ def reduce_stats(nblocks, checksum, elapsed_s, device):
     """All-reduce run statistics.  Returns (total blocks, summed checksum[3], max elapsed seconds)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return int(nblocks), checksum.detach().to("cpu"), float(elapsed_s)
+    if dist.get_backend() == "gloo":
+        device = "cpu"                       # gloo reduces host tensors (the CPU tests; bench.py --dist-backend gloo)
     sums = torch.cat([torch.tensor([float(nblocks)], dtype=torch.float64, device=device), checksum.to(device)])
     dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     tmax = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)

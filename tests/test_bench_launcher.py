@@ -77,3 +77,31 @@ def test_roofline_traffic_comes_from_the_committed_pmc_summary():
         assert 1.0 <= tr["bytes"] / (bytes_per_block * 4096) < 1.05
     assert bench.pmc_traffic("k_row_receive<64, 9, 2, 1, 0, false>", 4097) is None
     assert set(bench.CONFIGS) == {"cfg2", "cfg3", "cfg4", "cfg5"} and bench.CONFIGS["cfg4"]["total"] == bench.CONFIGS["cfg5"]["total"] == 65536
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_whole_multi_rank_bench_path_on_one_gpu():
+    """The N > 1 path of bench.py END TO END on the one GPU of the test box: `--dist-backend gloo` lets the ranks share the device, everything
+    else is the path the driver runs on a multi-GPU node (launcher, rendezvous, gfdm_amd.sharding.ShardedBatch shards, the HIP kernels on
+    every rank's shard, barrier-bracketed timing, all-reduced statistics).  BASELINE configs[3] is strong-scaled: the all-reduced output
+    checksum of the first ring slot must not depend on the number of ranks."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = {}
+    for n in (1, 2, 3):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "gloo", "--config", "cfg4", "--batch", "6000",
+                            "--steps", "3", "--warmup", "1", "--sustained-seconds", "0", "--no-cpu-baseline", "--ring-mib", "512"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        res[n] = json.loads(lines[0])
+    assert [res[n]["n_gpus"] for n in (1, 2, 3)] == [1, 2, 3]
+    assert all(r["scaling"] == "strong" and r["config"]["blocks_per_step_all_gpus"] == 6000 for r in res.values())
+    assert [res[n]["config"]["batch_per_gpu"] for n in (1, 2, 3)] == [6000, 3000, 2000]
+    for n in (2, 3):
+        for a, b in zip(res[1]["output_checksum"], res[n]["output_checksum"]):
+            assert abs(a - b) <= 1e-9 * max(1.0, abs(a))
+    assert all(r["value"] > 1e6 and r["roofline"]["frac"] > 0.05 for r in res.values())
