@@ -1159,7 +1159,7 @@ int est_run_device(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, v
 {
     if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
     return run_device(c->plan, out, in, nframes, [&]() {
-        if (c->plan.family == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
+        if (c->plan.current_family() == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
             return gfdm::launch_rowlane_estimate(c->ep, static_cast<cf*>(out), static_cast<const cf*>(in), nframes, static_cast<hipStream_t>(stream));
         if (c->plan.family == gfdm::FAMILY_ROWLANE_JIT && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
             return gfdm::jit_launch_estimate(&c->plan.jit, c->ep, static_cast<cf*>(out), static_cast<const cf*>(in), nframes, static_cast<hipStream_t>(stream));
@@ -1174,7 +1174,7 @@ int est_run_host(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, flo
     if (nframes < 0) return fail(GFDM_HIP_EINVAL, "negative frame count");
     const size_t nout = (size_t)nframes * est_stage_elems(c->ep, out_stage), nin = (size_t)nframes * est_stage_elems(c->ep, in_stage);
     return run_host_sized(c->plan, out, nout, in, nin, nullptr, 0, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
-        if (c->plan.family == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
+        if (c->plan.current_family() == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
             return gfdm::launch_rowlane_estimate(c->ep, o, i, nframes, s);
         if (c->plan.family == gfdm::FAMILY_ROWLANE_JIT && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
             return gfdm::jit_launch_estimate(&c->plan.jit, c->ep, o, i, nframes, s);
@@ -1239,7 +1239,17 @@ int gfdm_hip_channel_estimator_create(gfdm_hip_channel_estimator** out, int time
     if (!g_force_generic.load()) {
         std::string why;
         if (gfdm::rowlane_supports_estimate(timeslots, K)) c->plan.family = gfdm::FAMILY_ROWLANE;
-        else if (g_jit.load() && gfdm::jit_eligible(timeslots, K, 2) && gfdm::jit_prepare_estimate(timeslots, K, why)) c->plan.family = gfdm::FAMILY_ROWLANE_JIT;
+        else if (g_jit.load() && gfdm::jit_eligible(timeslots, K, 2)) {
+            // the same policy as plan_create: a compile that takes more than seconds runs in the background, the generic kernels serve meanwhile
+            int mode = g_jit.load();
+            if (mode == 3) mode = (timeslots <= 16 || gfdm::jit_cached(timeslots, K, 2, gfdm::JIT_PART_EST)) ? 1 : 2;
+            if (mode == 2) {
+                c->plan.jit_pending = std::make_shared<std::atomic<int>>(0);
+                gfdm::jit_prepare_async(timeslots, K, 2, 1u << gfdm::JIT_PART_EST, device, c->plan.jit_pending);
+            } else if (gfdm::jit_prepare_estimate(timeslots, K, why)) {
+                c->plan.family = gfdm::FAMILY_ROWLANE_JIT;
+            }
+        }
     }
     c->plan.kernel_name = c->plan.family == gfdm::FAMILY_ROWLANE ? "rowlane" : c->plan.family == gfdm::FAMILY_ROWLANE_JIT ? "rowlane_jit" : "generic_lds";
     *out = c.release();
@@ -1253,7 +1263,7 @@ int gfdm_hip_channel_estimator_active_subcarriers(const gfdm_hip_channel_estimat
 int gfdm_hip_channel_estimator_frame_len(const gfdm_hip_channel_estimator* c) { return c ? c->ep.M * c->ep.K : GFDM_HIP_EINVAL; }
 int gfdm_hip_channel_estimator_is_dc_free(const gfdm_hip_channel_estimator* c) { return c ? c->ep.dc_free : GFDM_HIP_EINVAL; }
 int gfdm_hip_channel_estimator_filtered_len(const gfdm_hip_channel_estimator* c) { return c ? c->ep.n_est : GFDM_HIP_EINVAL; }
-const char* gfdm_hip_channel_estimator_kernel_name(const gfdm_hip_channel_estimator* c) { return c ? c->plan.kernel_name.c_str() : ""; }
+const char* gfdm_hip_channel_estimator_kernel_name(const gfdm_hip_channel_estimator* c) { return c ? plan_kernel_name(c->plan) : ""; }
 
 int gfdm_hip_channel_estimator_preamble_filter_taps(const gfdm_hip_channel_estimator* c, float* out)
 {

@@ -748,6 +748,18 @@ def test_run_time_instantiation_off_the_constructors_critical_path(tmp_path, mon
         gfdm_amd.precompile(9, 64, 2)                                   # compiled into the library: nothing to do, no error
         with pytest.raises(gfdm_amd.GfdmHipError):
             gfdm_amd.precompile(127, 16, 2)                             # generic family only
+        # the channel estimator handle follows the same policy (its kernel is the fifth part of a shape)
+        Me, Ke, Ae = 17, 32, 24
+        pre = np.tile(np.fft.ifft(np.exp(2j * np.pi * rng.random(Ke))) * np.sqrt(Ke), 2)
+        rx_pre = (np.tile(pre, (3, 1)) * np.exp(0.3j * np.arange(3))[:, None]).astype(np.complex64)
+        est = gfdm_amd.ChannelEstimator(Me, Ke, Ae, True, 1, pre)
+        assert est.kernel_name() == "generic_lds"
+        ref_e = R.estimate_frame(rx_pre, pre.astype(np.complex64), Me, Ke, Ae, True)
+        assert rel_err(est.estimate_frame(rx_pre), ref_e) < TOL
+        deadline = time.perf_counter() + 300
+        while est.kernel_name() != "rowlane_jit" and time.perf_counter() < deadline:
+            time.sleep(0.25)
+        assert est.kernel_name() == "rowlane_jit" and rel_err(est.estimate_frame(rx_pre), ref_e) < TOL
         # JIT_BACKGROUND for any shape, also a quick one
         gfdm_amd.set_jit(gfdm_amd.JIT_BACKGROUND)
         mod = gfdm_amd.Modulator(7, 8, 2, get_frequency_domain_filter("rrc", 0.3, 7, 8, 2))
