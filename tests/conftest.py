@@ -40,7 +40,7 @@ def _jit_inside_the_constructor():
 def golden_names():
     """kernel-path fixtures (make_golden.py); the composite-transmitter fixtures (make_golden_tx.py) are tx_*"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("tx_", "est_", "ic_", "snr_"))]
+    return [n for n in names if not n.startswith(("tx_", "est_", "ic_", "snr_", "rxl_"))]
 
 
 def ic_golden_names():
@@ -81,6 +81,19 @@ def load_snr_golden(name):
     for k in ("M", "K", "A"):
         g[k] = int(g[k])
     g["snr_db"] = float(g["snr_db"])
+    return g
+
+
+def rx_overlap_golden_names():
+    """receiver at any overlap against pygfdm's overlap-generic model gfdm_demodulate_fft_loop (make_golden_rx_overlap.py)"""
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "rxl_*.npz")))
+
+
+def load_rx_overlap_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    for k in ("M", "K", "L"):
+        g[k] = int(g[k])
     return g
 
 

@@ -89,6 +89,24 @@ def test_receiver_is_transpose_of_modulator(name):
     assert abs(lhs - rhs) / abs(lhs) < 1e-11
 
 
+@pytest.mark.parametrize("name", __import__("conftest").rx_overlap_golden_names())
+def test_receiver_oracles_match_pygfdm_at_any_overlap(name):
+    """The receiver's filter stage for overlap 4, 6, 8 (lib/receiver_kernel_cc.cc:165-192) against the reference's overlap-generic Python
+    model gfdm_demodulate_fft_loop (python/pygfdm/gfdm_receiver.py:190-199; tests/golden/make_golden_rx_overlap.py) -- the model
+    make_golden.py uses is valid for overlap 2 only.  Both oracles, modulated and arbitrary input."""
+    from conftest import load_rx_overlap_golden
+    g = load_rx_overlap_golden(name)
+    M, K, L = g["M"], g["K"], g["L"]
+    nt = R.normalize_taps(g["taps"], M)
+    co = c_oracle.COracle(M, K, L, g["taps"])
+    for x, ref in ((g["frames"], g["pygfdm_demodulate_fft_loop"]), (g["gauss"], g["pygfdm_demodulate_fft_loop_gauss"])):
+        assert rel_err(R.demodulate(x, nt, M, K, L), ref) < 1e-12
+        assert rel_err(co.demodulate(x), ref) < 1e-6
+        # ... and S itself: IDFT_M(S)/M = model output  <=>  S = DFT_M(model output)
+        S = R.fft_filter_downsample(x, nt, M, K, L)
+        assert rel_err(S, np.fft.fft(ref.reshape(-1, K, M), axis=-1).reshape(ref.shape)) < 1e-12
+
+
 def test_ic_stage_oracles_match_pygfdm():
     """The IC stage pinned by the reference's Python model (tests/golden/make_golden_ic.py): gfdm_get_ic_f_taps ==
     ic_filter_taps, gfdm_remove_sc_interference == cancel_sc_interference (real RRC taps and complex asymmetric taps), and

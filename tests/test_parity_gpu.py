@@ -80,6 +80,28 @@ def test_golden_demodulator(name):
     assert rel_err(dem.demodulate_batch(g["frame_through_channel"], g["f_eq"]), g["pygfdm_demodulate"]) < TOL
 
 
+@pytest.mark.parametrize("name", __import__("conftest").rx_overlap_golden_names())
+def test_golden_demodulator_any_overlap(name):
+    """The receiver at overlap 4, 6, 8 (BASELINE configs[3], the reference's M=127 K=16 overlap-4 shape, ...) against pygfdm's
+    overlap-generic model gfdm_demodulate_fft_loop (tests/golden/make_golden_rx_overlap.py): pybind11 per block and batched, ctypes,
+    and the frequency-domain output S = DFT_M of the model's symbols."""
+    import gfdm_amd
+    import gfdm_python
+    from conftest import load_rx_overlap_golden
+    g = load_rx_overlap_golden(name)
+    M, K, L = g["M"], g["K"], g["L"]
+    dem = gfdm_python.Demodulator(M, K, L, g["taps"])
+    hd = gfdm_amd.Demodulator(M, K, L, g["taps"])
+    for x, ref in ((g["frames"], g["pygfdm_demodulate_fft_loop"]), (g["gauss"], g["pygfdm_demodulate_fft_loop_gauss"])):
+        for b in range(x.shape[0]):
+            check_err("golden_rx_overlap_%s" % name, rel_err(dem.demodulate(x[b]), ref[b]), TOL)
+        check_err("golden_rx_overlap_%s" % name, rel_err(dem.demodulate_batch(x), ref), TOL)
+        check_err("golden_rx_overlap_%s" % name, rel_err(hd.demodulate(x), ref), TOL)
+        S = np.fft.fft(ref.reshape(-1, K, M), axis=-1).reshape(ref.shape)
+        check_err("golden_rx_overlap_S_%s" % name, rel_err(hd.fft_filter_downsample(x), S), TOL)
+    assert_places(dem.demodulate(g["frames"][0]), g["pygfdm_demodulate_fft_loop"][0], 5)
+
+
 @pytest.mark.parametrize("name", ic_golden_names())
 def test_golden_ic_stage(name):
     """The IC stage against the reference's Python model (tests/golden/make_golden_ic.py; python/pygfdm/gfdm_receiver.py:99-114):
