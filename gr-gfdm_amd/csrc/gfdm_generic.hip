@@ -67,42 +67,82 @@ __device__ __forceinline__ DevicePlan stage_tables(const DevicePlan& p, unsigned
     return q;                                   // the caller's first __syncthreads() publishes the tables
 }
 
-// One pass over v_p and the roots w_p = W_M^{p m} yields TWO outputs of the direct DFT, m and M - m: W_M^{p (M - m)} = conj(w_p), so with
-// v = a + j b, w = c + j s the sums P1 = sum a c, P2 = sum b s, P3 = sum a s, P4 = sum b c give  sum v w = (P1 - P2, P3 + P4)  and
-// sum v conj(w) = (P1 + P2, P4 - P3): four multiply-adds and two LDS reads per term for the pair instead of eight and four.
+// One pass over the samples v_p and the roots w_p = W_M^{p m} yields TWO outputs of the direct DFT, m and M - m (W_M^{p (M - m)} = conj(w_p)),
+// and it takes the samples in PAIRS as well: w_{M - p} = conj(w_p), so with a = v_p + v_{M-p}, b = v_p - v_{M-p} and w_p = (c, s)
+//     v_p w_p + v_{M-p} conj(w_p) = a c + j b s          v_p conj(w_p) + v_{M-p} w_p = a c - j b s
+// i.e. the four sums Q1 = sum a.x c, Q2 = sum a.y c, Q3 = sum b.x s, Q4 = sum b.y s give  sum v w = (Q1 - Q4, Q2 + Q3)  and
+// sum v conj(w) = (Q1 + Q4, Q2 - Q3): four multiply-adds and ONE root per two samples and two outputs (the symmetric form of gfdm_dft.h's
+// prime codelet, table driven).  The sample p = 0 enters through the start values, the middle sample of an even M through add(v, 0, w).
 struct DftPair {
-    float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
-    __device__ __forceinline__ void add(cf v, cf w)
+    float q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f;
+    __device__ __forceinline__ void start(cf v0) { q1 = v0.x; q2 = v0.y; }
+    __device__ __forceinline__ void add(cf a, cf b, cf w)
     {
-        p1 = fmaf(v.x, w.x, p1);
-        p2 = fmaf(v.y, w.y, p2);
-        p3 = fmaf(v.x, w.y, p3);
-        p4 = fmaf(v.y, w.x, p4);
+        q1 = fmaf(a.x, w.x, q1);
+        q2 = fmaf(a.y, w.x, q2);
+        q3 = fmaf(b.x, w.y, q3);
+        q4 = fmaf(b.y, w.y, q4);
     }
-    __device__ __forceinline__ cf with_root() const { return make_float2(p1 - p2, p3 + p4); }        // sum v w
-    __device__ __forceinline__ cf with_conj() const { return make_float2(p1 + p2, p4 - p3); }        // sum v conj(w)
+    __device__ __forceinline__ cf with_root() const { return make_float2(q1 - q4, q2 + q3); }        // sum v w
+    __device__ __forceinline__ cf with_conj() const { return make_float2(q1 + q4, q2 - q3); }        // sum v conj(w)
 };
+
+// The direct timeslot transforms of this family, one loop for all of them: work items (row r < rows, output pair m < H = M/2 + 1), each the sum over
+// p < M of src(r, p) W_M^{p m} in the paired form above, handed to fin(r, m, acc).  These loops are LDS-bound -- two LDS reads (sample, root) per
+// four multiply-adds -- so a thread takes NB CONSECUTIVE pairs of one row at a time where the block has enough work for that (register blocking:
+// one sample pair feeds NB output pairs).  ROWFAST: neighbouring threads
+// take neighbouring rows of one pair block (the modulator's last stage, whose stores want the row index fastest), else neighbouring pair blocks.
+template <int NB, bool ROWFAST, class Src, class Fin>
+__device__ __forceinline__ void paired_dft_blocked(int rows, int M, const cf* __restrict__ wM, Src src, Fin fin)
+{
+    const int H = M / 2 + 1, HB = (H + NB - 1) / NB, HP = (M - 1) / 2;
+    DivStep ix(threadIdx.x, GT, ROWFAST ? rows : HB);
+    for (int idx = threadIdx.x; idx < rows * HB; idx += GT, ix.next()) {
+        const int r = ROWFAST ? ix.r : ix.q, m0 = (ROWFAST ? ix.q : ix.r) * NB;
+        const cf v0 = src(r, 0);
+        DftPair acc[NB];
+        int e[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { acc[j].start(v0); e[j] = m0 + j; }     // p m mod M for p = 1 (a pair index past H - 1 in the last block is still < M)
+        for (int p = 1; p <= HP; ++p) {
+            const cf vp = src(r, p), vq = src(r, M - p);
+            const cf a = cadd(vp, vq), b = csub(vp, vq);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                acc[j].add(a, b, wM[e[j]]);
+                e[j] += m0 + j;
+                if (e[j] >= M) e[j] -= M;
+            }
+        }
+        if ((M & 1) == 0) {                               // the middle sample of an even M: W_M^{(M/2) m} = +-1
+            const cf v = src(r, M / 2);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[j].add(v, make_float2(0.f, 0.f), wM[e[j]]);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (m0 + j < H) fin(r, m0 + j, acc[j]);
+    }
+}
+
+template <bool ROWFAST, class Src, class Fin>
+__device__ __forceinline__ void paired_dft(int rows, int M, const cf* __restrict__ wM, Src src, Fin fin)
+{
+    if (rows * (M / 2 + 1) >= 4 * GT) paired_dft_blocked<4, ROWFAST>(rows, M, wM, src, fin);
+    else paired_dft_blocked<1, ROWFAST>(rows, M, wM, src, fin);
+}
 
 // dst[r*M + m] = scale * sum_p src[r*rs + p*ps] * W_M^{+-(p m)}      (dst may be LDS or global); one work item per pair (m, M - m)
 template <bool INV>
 __device__ void row_dft(cf* dst, const cf* src, int rows, int M, int rs, int ps, const cf* __restrict__ wM, float scale)
 {
-    const int H = M / 2 + 1;
-    DivStep ix(threadIdx.x, GT, H);
-    for (int idx = threadIdx.x; idx < rows * H; idx += GT, ix.next()) {
-        const int r = ix.q, m = ix.r, m2 = (m == 0) ? 0 : M - m;
-        DftPair acc;
-        int e = 0;
-        const cf* row = src + r * rs;
-        for (int p = 0; p < M; ++p) {
-            acc.add(row[p * ps], wM[e]);
-            e += m;
-            if (e >= M) e -= M;
-        }
-        const cf ya = INV ? acc.with_conj() : acc.with_root(), yb = INV ? acc.with_root() : acc.with_conj();
-        dst[r * M + m] = make_float2(ya.x * scale, ya.y * scale);
-        if (m2 != m) dst[r * M + m2] = make_float2(yb.x * scale, yb.y * scale);
-    }
+    paired_dft<false>(rows, M, wM, [&](int r, int p) { return src[r * rs + p * ps]; },
+                      [&](int r, int m, const DftPair& acc) {
+                          const int m2 = (m == 0) ? 0 : M - m;
+                          const cf ya = INV ? acc.with_conj() : acc.with_root(), yb = INV ? acc.with_root() : acc.with_conj();
+                          dst[r * M + m] = make_float2(ya.x * scale, ya.y * scale);
+                          if (m2 != m) dst[r * M + m2] = make_float2(yb.x * scale, yb.y * scale);
+                      });
 }
 
 // K-point transform along the subcarrier axis of a [K][M] LDS tile, all M columns at once: mixed-radix Stockham autosort
@@ -132,41 +172,60 @@ __device__ cf* col_fft(cf* a, cf* b, const DevicePlan& p)
         const int r = next_radix(n), m = n / r;
         const int rstep = K / r;                                  // W_r^1 = wK[K / r]
         const int total = m * s * M;                              // (butterfly, column) pairs of this pass
-        DivStep bx(threadIdx.x, GT, M);
-        for (int idx = threadIdx.x; idx < total; idx += GT, bx.next()) {
-            const int bf = bx.q, col = bx.r;
-            const int pp = (s == 1) ? bf : bf / s, q = bf - pp * s;
-            const cf* xin = x + (q + s * pp) * M + col;           // element k at xin[s m k M]
-            cf* yout = y + (q + s * r * pp) * M + col;            // element j at yout[s j M]
-            const int in_step = s * m * M, out_step = s * M;
-            if (r == 4) {
-                const cf x0 = xin[0], x1 = xin[in_step], x2 = xin[2 * in_step], x3 = xin[3 * in_step];
-                const cf apc = cadd(x0, x2), amc = csub(x0, x2), bpd = cadd(x1, x3), t = csub(x1, x3);
-                const cf bmd = INV ? make_float2(-t.y, t.x) : make_float2(t.y, -t.x);        // -+ j (x1 - x3)
-                const cf y0 = cadd(apc, bpd), y1 = cadd(amc, bmd), y2 = csub(apc, bpd), y3 = csub(amc, bmd);
-                const int e = pp * s;                             // W_n^{p j} = wK[p j s]
-                yout[0] = y0;
-                const cf w1 = wK[e], w2 = wK[2 * e], w3 = wK[3 * e];
-                yout[out_step] = INV ? cmulj(y1, w1) : cmul(y1, w1);
-                yout[2 * out_step] = INV ? cmulj(y2, w2) : cmul(y2, w2);
-                yout[3 * out_step] = INV ? cmulj(y3, w3) : cmul(y3, w3);
-            } else if (r == 2) {
-                const cf u = xin[0], v = xin[in_step];
-                const cf w = wK[pp * s], d = csub(u, v);
-                yout[0] = cadd(u, v);
-                yout[out_step] = INV ? cmulj(d, w) : cmul(d, w);
-            } else {
-                for (int j = 0; j < r; ++j) {
-                    cf acc = make_float2(0.f, 0.f);
-                    int e = 0;                                    // j k K / r  (mod K)
-                    for (int k = 0; k < r; ++k) {
-                        const cf w = wK[e];
-                        acc = INV ? cfmaj(xin[k * in_step], w, acc) : cfma(xin[k * in_step], w, acc);
-                        e += j * rstep;
-                        if (e >= K) e -= K;
-                    }
-                    const cf w = wK[(int)(((long long)pp * j * s) % K)];
-                    yout[j * out_step] = INV ? cmulj(acc, w) : cmul(acc, w);
+        const int in_step = s * m * M, out_step = s * M;
+        if (r == 4 || r == 2) {
+            DivStep bx(threadIdx.x, GT, M);
+            for (int idx = threadIdx.x; idx < total; idx += GT, bx.next()) {
+                const int bf = bx.q, col = bx.r;
+                const int pp = (s == 1) ? bf : bf / s, q = bf - pp * s;
+                const cf* xin = x + (q + s * pp) * M + col;           // element k at xin[s m k M]
+                cf* yout = y + (q + s * r * pp) * M + col;            // element j at yout[s j M]
+                if (r == 4) {
+                    const cf x0 = xin[0], x1 = xin[in_step], x2 = xin[2 * in_step], x3 = xin[3 * in_step];
+                    const cf apc = cadd(x0, x2), amc = csub(x0, x2), bpd = cadd(x1, x3), t = csub(x1, x3);
+                    const cf bmd = INV ? make_float2(-t.y, t.x) : make_float2(t.y, -t.x);        // -+ j (x1 - x3)
+                    const cf y0 = cadd(apc, bpd), y1 = cadd(amc, bmd), y2 = csub(apc, bpd), y3 = csub(amc, bmd);
+                    const int e = pp * s;                             // W_n^{p j} = wK[p j s]
+                    yout[0] = y0;
+                    const cf w1 = wK[e], w2 = wK[2 * e], w3 = wK[3 * e];
+                    yout[out_step] = INV ? cmulj(y1, w1) : cmul(y1, w1);
+                    yout[2 * out_step] = INV ? cmulj(y2, w2) : cmul(y2, w2);
+                    yout[3 * out_step] = INV ? cmulj(y3, w3) : cmul(y3, w3);
+                } else {
+                    const cf u = xin[0], v = xin[in_step];
+                    const cf w = wK[pp * s], d = csub(u, v);
+                    yout[0] = cadd(u, v);
+                    yout[out_step] = INV ? cmulj(d, w) : cmul(d, w);
+                }
+            }
+        } else {
+            // an odd prime radix (a prime K is ONE such pass, i.e. the direct DFT): one work item per (output pair j / r - j, butterfly, column),
+            // not per butterfly -- a prime K has only M butterflies -- in the paired form of DftPair: r / 2 steps of two samples and one root
+            const int JH = r / 2 + 1, HP = (r - 1) / 2, nbf = m * s;
+            DivStep bx(threadIdx.x, GT, M);
+            for (int idx = threadIdx.x; idx < total * JH; idx += GT, bx.next()) {
+                const int jb = bx.q, col = bx.r;
+                const int j = (nbf == 1) ? jb : jb / nbf, bf = jb - j * nbf;
+                const int pp = (s == 1) ? bf : bf / s, q = bf - pp * s;
+                const cf* xin = x + (q + s * pp) * M + col;
+                cf* yout = y + (q + s * r * pp) * M + col;
+                DftPair acc;
+                acc.start(xin[0]);
+                const int de = j * rstep;                             // W_r^{j k} = wK[j k K / r mod K]
+                int e = de;
+                for (int k = 1; k <= HP; ++k) {
+                    const cf vp = xin[k * in_step], vq = xin[(r - k) * in_step];
+                    acc.add(cadd(vp, vq), csub(vp, vq), wK[e]);
+                    e += de;
+                    if (e >= K) e -= K;
+                }
+                const int j2 = (j == 0) ? 0 : r - j;
+                const cf ya = INV ? acc.with_conj() : acc.with_root(), yb = INV ? acc.with_root() : acc.with_conj();
+                const cf wa = wK[(int)(((long long)pp * j * s) % K)];
+                yout[j * out_step] = INV ? cmulj(ya, wa) : cmul(ya, wa);
+                if (j2 != j) {
+                    const cf wb = wK[(int)(((long long)pp * j2 * s) % K)];
+                    yout[j2 * out_step] = INV ? cmulj(yb, wb) : cmul(yb, wb);
                 }
             }
         }
@@ -217,22 +276,13 @@ __device__ __forceinline__ cf decide(cf x, const IcParams& ic)
 __device__ void cancel_rows(cf* dst, const cf* td, const cf* fd, const DevicePlan& p)
 {
     const int M = p.M, K = p.K;
-    const int H = M / 2 + 1;
-    DivStep ix(threadIdx.x, GT, H);
-    for (int idx = threadIdx.x; idx < K * H; idx += GT, ix.next()) {
-        const int k = ix.q, m = ix.r, m2 = (m == 0) ? 0 : M - m;
-        const cf* prev = td + (k == 0 ? K - 1 : k - 1) * M;
-        const cf* next = td + (k == K - 1 ? 0 : k + 1) * M;
-        DftPair acc;
-        int e = 0;
-        for (int q = 0; q < M; ++q) {
-            acc.add(cadd(prev[q], next[q]), p.wM[e]);
-            e += m;
-            if (e >= M) e -= M;
-        }
-        dst[k * M + m] = csub(fd[k * M + m], cmul(p.ictaps[m], acc.with_root()));
-        if (m2 != m) dst[k * M + m2] = csub(fd[k * M + m2], cmul(p.ictaps[m2], acc.with_conj()));
-    }
+    paired_dft<false>(K, M, p.wM,
+                      [&](int k, int q) { return cadd(td[(k == 0 ? K - 1 : k - 1) * M + q], td[(k == K - 1 ? 0 : k + 1) * M + q]); },
+                      [&](int k, int m, const DftPair& acc) {
+                          const int m2 = (m == 0) ? 0 : M - m;
+                          dst[k * M + m] = csub(fd[k * M + m], cmul(p.ictaps[m], acc.with_root()));
+                          if (m2 != m) dst[k * M + m2] = csub(fd[k * M + m2], cmul(p.ictaps[m2], acc.with_conj()));
+                      });
 }
 
 // resource demapper in the store stage: active subcarriers only, mapper order (resource_mapper_kernel_cc.cc:91-106,136-163)
@@ -303,26 +353,19 @@ __global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan pg, TxParams
     __syncthreads();
     // x[K p + q] = (1/N) sum_m u[q][m] conj(W_M^{p m});  q fastest so the global store is coalesced   :137-140
     const float scale = 1.f / (float)N;
-    DivStep px(threadIdx.x, GT, K);
-    for (int idx = threadIdx.x; idx < K * (M / 2 + 1); idx += GT, px.next()) {       // time slots pp and M - pp from one pass (DftPair)
-        const int pp = px.q, q = px.r, pp2 = (pp == 0) ? 0 : M - pp;
-        DftPair acc;
-        int e = 0;
-        for (int m = 0; m < M; ++m) {
-            acc.add(u[q * M + m], p.wM[e]);
-            e += pp;
-            if (e >= M) e -= M;
-        }
-        const cf ya = acc.with_conj(), yb = acc.with_root();           // inverse transform: conj(W_M^{p m}) for pp, the root itself for M - pp
-        const cf y = make_float2(ya.x * scale, ya.y * scale);
-        if (tx.framed) tx_store_sample(tx, blk, N, K * pp + q, y);      // cyclic prefix / suffix + ramp, every port
-        else o[K * pp + q] = y;
-        if (pp2 != pp) {
-            const cf y2 = make_float2(yb.x * scale, yb.y * scale);
-            if (tx.framed) tx_store_sample(tx, blk, N, K * pp2 + q, y2);
-            else o[K * pp2 + q] = y2;
-        }
-    }
+    paired_dft<true>(K, M, p.wM, [&](int q, int m) { return u[q * M + m]; },
+                     [&](int q, int pp, const DftPair& acc) {                    // time slots pp and M - pp from one pass
+                         const int pp2 = (pp == 0) ? 0 : M - pp;
+                         const cf ya = acc.with_conj(), yb = acc.with_root();    // inverse transform: conj(W_M^{p m}) for pp, the root itself for M - pp
+                         const cf y = make_float2(ya.x * scale, ya.y * scale);
+                         if (tx.framed) tx_store_sample(tx, blk, N, K * pp + q, y);      // cyclic prefix / suffix + ramp, every port
+                         else o[K * pp + q] = y;
+                         if (pp2 != pp) {
+                             const cf y2 = make_float2(yb.x * scale, yb.y * scale);
+                             if (tx.framed) tx_store_sample(tx, blk, N, K * pp2 + q, y2);
+                             else o[K * pp2 + q] = y2;
+                         }
+                     });
     if (tx.framed) tx_store_preamble(tx, blk, threadIdx.x, GT);
 }
 
@@ -364,20 +407,12 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams 
     for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
     __syncthreads();
     // A[q][m] = W_N^{q m} * sum_p x[K p + q] W_M^{p m}
-    const int MH = M / 2 + 1;                                      // outputs m and M - m from one pass (DftPair)
-    DivStep ax(threadIdx.x, GT, MH);
-    for (int idx = threadIdx.x; idx < K * MH; idx += GT, ax.next()) {
-        const int q = ax.q, m = ax.r, m2 = (m == 0) ? 0 : M - m;
-        DftPair acc;
-        int e = 0;
-        for (int pp = 0; pp < M; ++pp) {
-            acc.add(t1[K * pp + q], p.wM[e]);
-            e += m;
-            if (e >= M) e -= M;
-        }
-        t0[q * M + m] = cmul(acc.with_root(), p.wN[q * m]);
-        if (m2 != m) t0[q * M + m2] = cmul(acc.with_conj(), p.wN[q * m2]);
-    }
+    paired_dft<false>(K, M, p.wM, [&](int q, int pp) { return t1[K * pp + q]; },       // outputs m and M - m from one pass (DftPair)
+                      [&](int q, int m, const DftPair& acc) {
+                          const int m2 = (m == 0) ? 0 : M - m;
+                          t0[q * M + m] = cmul(acc.with_root(), p.wN[q * m]);
+                          if (m2 != m) t0[q * M + m2] = cmul(acc.with_conj(), p.wN[q * m2]);
+                      });
     __syncthreads();
     cf* X = col_fft<false>(t0, t1, p);                             // X[j][m] = FFT_N(x)[M j + m]       :304-305
     cf* U = (X == t0) ? t1 : t0;
