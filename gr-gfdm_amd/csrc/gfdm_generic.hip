@@ -67,6 +67,26 @@ __device__ __forceinline__ DevicePlan stage_tables(const DevicePlan& p, unsigned
     return q;                                   // the caller's first __syncthreads() publishes the tables
 }
 
+// Global -> LDS copy of a block with FOUR loads of a thread in flight (a plain `dst[i] = src[i]` loop of unknown length waits for every load before
+// it issues the next one: eight DRAM round trips per thread for a 2000-sample block).  op(value, index) is applied on the way.
+template <class Op>
+__device__ __forceinline__ void stream_in(cf* dst, const cf* __restrict__ src, int n, Op op)
+{
+    int idx = threadIdx.x;
+    for (; idx + 3 * GT < n; idx += 4 * GT) {
+        const cf a = src[idx], b = src[idx + GT], c = src[idx + 2 * GT], d = src[idx + 3 * GT];
+        dst[idx] = op(a, idx);
+        dst[idx + GT] = op(b, idx + GT);
+        dst[idx + 2 * GT] = op(c, idx + 2 * GT);
+        dst[idx + 3 * GT] = op(d, idx + 3 * GT);
+    }
+    for (; idx < n; idx += GT) dst[idx] = op(src[idx], idx);
+}
+__device__ __forceinline__ void stream_in(cf* dst, const cf* __restrict__ src, int n)
+{
+    stream_in(dst, src, n, [](cf v, int) { return v; });
+}
+
 // One pass over the samples v_p and the roots w_p = W_M^{p m} yields TWO outputs of the direct DFT, m and M - m (W_M^{p (M - m)} = conj(w_p)),
 // and it takes the samples in PAIRS as well: w_{M - p} = conj(w_p), so with a = v_p + v_{M-p}, b = v_p - v_{M-p} and w_p = (c, s)
 //     v_p w_p + v_{M-p} conj(w_p) = a c + j b s          v_p conj(w_p) + v_{M-p} w_p = a c - j b s
@@ -125,18 +145,125 @@ __device__ __forceinline__ void paired_dft_blocked(int rows, int M, const cf* __
     }
 }
 
+// The same transforms on the matrix cores (from MX_DFT_MIN_M timeslots on): the four sums above are products of CONSTANT matrices with the block's
+// samples,  [Q1 | Q2] = C [a.x | a.y],  [Q3 | Q4] = S [b.x | b.y],  C[m][p] = Re W_M^{m p}, S[m][p] = Im W_M^{m p}  (rows: the H = M/2 + 1 output
+// pairs; columns: p = 0 -- the sample v_0 itself, C = 1 --, the sample pairs p = 1..(M-1)/2, the middle sample of an even M), i.e. real GEMMs of
+// H x ~M/2 x (2 x rows) per transform -- a dense contraction, f32 in, f32 sums (v_mfma_f32_16x16x4_f32), nothing reduced in precision.
+//   A operand: the handle's table DevicePlan::dftA (gfdm_hip_api.hip), [output tile][k-step][cos, sin][lane], read from global memory (L1 / L2 hits)
+//   B operand: the sums a and differences b of one 16-row group, written once into the LDS scratch xs as four planes [a.x][a.y][b.x][b.y] of
+//              [4 KS][16 rows] floats: the operand of k-step ks is the 64 consecutive floats at 64 ks (lane l: k = l >> 4, row l & 15, conflict-free)
+//   D: lane l holds the outputs m = 16 mt + 4 (l >> 4) + i, i < 4, of row l & 15: Q1..Q4 of one (row, output pair) end up in ONE lane, so the epilogue is
+//      the same fin(r, m, DftPair) as in the vector-ALU form.
+// A wavefront takes (output tile, row group) units; the scratch holds rtc row groups at a time (launch code: as many as keep the blocks per CU).
+struct MxDft {
+    const float* A;
+    float* xs;
+    int rtc, MT, KS;
+};
+
+typedef float mx_f4 __attribute__((ext_vector_type(4)));
+
+// A operands of one output tile, k-steps [ks0, ks0 + 16): 32 registers, loaded ahead of the code that waits for the samples (the table does not depend on them)
+struct MxA {
+    float c[16], s[16];
+    __device__ __forceinline__ void load(const float* __restrict__ A, int ks0, int KS)
+    {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool in = ks0 + j < KS;                          // uniform
+            c[j] = in ? A[(ks0 + j) * 128] : 0.f;
+            s[j] = in ? A[(ks0 + j) * 128 + 64] : 0.f;
+        }
+    }
+};
+
+template <class Src, class Fin>
+__device__ __forceinline__ void mx_dft(const MxDft& mx, int rows, int M, Src src, Fin fin)
+{
+    const int H = M / 2 + 1, HP = (M - 1) / 2, KD = HP + 1 + ((M & 1) == 0 ? 1 : 0), KDp = 4 * mx.KS, RT = (rows + 15) / 16;
+    const int plane = KDp * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    MxA a;
+    int a_mt = -1;                                                 // the output tile whose first 16 k-steps sit in a
+    if (wave < mx.MT * ((RT < mx.rtc) ? RT : mx.rtc)) {
+        a_mt = wave % mx.MT;
+        a.load(mx.A + (size_t)a_mt * mx.KS * 128 + lane, 0, mx.KS);
+    }
+    for (int rt0 = 0; rt0 < RT; rt0 += mx.rtc) {
+        const int nrt = (RT - rt0 < mx.rtc) ? RT - rt0 : mx.rtc;
+        if (rt0) __syncthreads();                                  // the previous chunk's operands are spent
+        DivStep ix(threadIdx.x >> 4, GT >> 4, KDp);
+        for (int idx = threadIdx.x; idx < nrt * plane; idx += GT, ix.next()) {
+            const int n = idx & 15, kk = ix.r, rt = ix.q;
+            const int r = 16 * (rt0 + rt) + n;
+            cf va = make_float2(0.f, 0.f), vb = va;
+            if (r < rows && kk < KD) {
+                if (kk == 0) va = src(r, 0);
+                else if (kk <= HP) { const cf vp = src(r, kk), vq = src(r, M - kk); va = cadd(vp, vq); vb = csub(vp, vq); }
+                else va = src(r, M / 2);
+            }
+            float* x = mx.xs + (rt * 4) * plane + kk * 16 + n;
+            x[0] = va.x; x[plane] = va.y; x[2 * plane] = vb.x; x[3 * plane] = vb.y;
+        }
+        __syncthreads();
+        for (int u = wave; u < mx.MT * nrt; u += GT / 64) {
+            const int rt = u / mx.MT, mt = u - rt * mx.MT;
+            const float* __restrict__ A = mx.A + (size_t)mt * mx.KS * 128 + lane;
+            const float* X = mx.xs + (rt * 4) * plane + lane;
+            mx_f4 q1 = { 0.f, 0.f, 0.f, 0.f }, q2 = q1, q3 = q1, q4 = q1;
+            for (int ks0 = 0; ks0 < mx.KS; ks0 += 16) {
+                if (ks0 || mt != a_mt) {                          // (uniform) not the operands this wavefront holds
+                    a.load(A, ks0, mx.KS);
+                    a_mt = ks0 ? -1 : mt;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (ks0 + j < mx.KS) {                         // uniform
+                        const int ks = ks0 + j;
+                        const float ax = X[ks * 64], ay = X[plane + ks * 64], bx = X[2 * plane + ks * 64], by = X[3 * plane + ks * 64];
+                        q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.c[j], ax, q1, 0, 0, 0);
+                        q2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.c[j], ay, q2, 0, 0, 0);
+                        q3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.s[j], bx, q3, 0, 0, 0);
+                        q4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.s[j], by, q4, 0, 0, 0);
+                    }
+                }
+            }
+            const int r = 16 * (rt0 + rt) + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 16 * mt + 4 * (lane >> 4) + i;
+                if (m < H && r < rows) {
+                    DftPair acc;
+                    acc.q1 = q1[i]; acc.q2 = q2[i]; acc.q3 = q3[i]; acc.q4 = q4[i];
+                    fin(r, m, acc);
+                }
+            }
+        }
+    }
+}
+
+// kernels come in two instantiations: with the matrix-core transforms (an MxDft in hand) and without (NoMx: the vector-ALU loops; these do not
+// carry the accumulator registers of the other form, which would cost the small shapes their occupancy)
+struct NoMx {};
+
 template <bool ROWFAST, class Src, class Fin>
-__device__ __forceinline__ void paired_dft(int rows, int M, const cf* __restrict__ wM, Src src, Fin fin)
+__device__ __forceinline__ void paired_dft(const MxDft& mx, int rows, int M, const cf* __restrict__, Src src, Fin fin)
+{
+    mx_dft(mx, rows, M, src, fin);
+}
+
+template <bool ROWFAST, class Src, class Fin>
+__device__ __forceinline__ void paired_dft(const NoMx&, int rows, int M, const cf* __restrict__ wM, Src src, Fin fin)
 {
     if (rows * (M / 2 + 1) >= 4 * GT) paired_dft_blocked<4, ROWFAST>(rows, M, wM, src, fin);
     else paired_dft_blocked<1, ROWFAST>(rows, M, wM, src, fin);
 }
 
 // dst[r*M + m] = scale * sum_p src[r*rs + p*ps] * W_M^{+-(p m)}      (dst may be LDS or global); one work item per pair (m, M - m)
-template <bool INV>
-__device__ void row_dft(cf* dst, const cf* src, int rows, int M, int rs, int ps, const cf* __restrict__ wM, float scale)
+template <bool INV, class Mx>
+__device__ __forceinline__ void row_dft(const Mx& mx, cf* dst, const cf* src, int rows, int M, int rs, int ps, const cf* __restrict__ wM, float scale)
 {
-    paired_dft<false>(rows, M, wM, [&](int r, int p) { return src[r * rs + p * ps]; },
+    paired_dft<false>(mx, rows, M, wM, [&](int r, int p) { return src[r * rs + p * ps]; },
                       [&](int r, int m, const DftPair& acc) {
                           const int m2 = (m == 0) ? 0 : M - m;
                           const cf ya = INV ? acc.with_conj() : acc.with_root(), yb = INV ? acc.with_root() : acc.with_conj();
@@ -161,7 +288,7 @@ __device__ __forceinline__ int next_radix(int n)
 }
 
 template <bool INV>
-__device__ cf* col_fft(cf* a, cf* b, const DevicePlan& p)
+__device__ __forceinline__ cf* col_fft(cf* a, cf* b, const DevicePlan& p)
 {
     const int M = p.M, K = p.K;
     const cf* __restrict__ wK = p.wK;
@@ -239,7 +366,7 @@ __device__ cf* col_fft(cf* a, cf* b, const DevicePlan& p)
 
 // estimate_preamble_channel :118-145 -- K-point FFT of both preamble halves, times 0.5 / FFT(known half), summed.
 // a, b: LDS scratch of 2K each; dst: K bins (LDS or global).  Caller syncs afterwards.
-__device__ void estimate_preamble_bins(const EstPlan& e, const cf* __restrict__ rx, cf* a, cf* b, cf* dst)
+__device__ __forceinline__ void estimate_preamble_bins(const EstPlan& e, const cf* __restrict__ rx, cf* a, cf* b, cf* dst)
 {
     const int K = e.K;
     for (int i = threadIdx.x; i < 2 * K; i += GT) {
@@ -272,11 +399,34 @@ __device__ __forceinline__ cf decide(cf x, const IcParams& ic)
     return ic.points[idx];
 }
 
+// calculate_phase_offset (adv:78-91): exp(j phi), phi = mean over the active symbols of arg(decision) - arg(symbol); red: GT floats of LDS
+__device__ __forceinline__ cf phase_rotation(const cf* D, const IcParams& ic, float* red, int M)
+{
+    float acc = 0.f;
+    for (int idx = threadIdx.x; idx < ic.n_active * M; idx += GT) {
+        const int a = idx / M, m = idx - a * M;
+        const cf v = D[ic.smap[a] * M + m];
+        const cf d = decide(v, ic);
+        acc += atan2f(d.y, d.x) - atan2f(v.y, v.x);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = GT / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float phi = red[0] / (float)(ic.n_active * M);
+    float sn, cs;
+    sincosf(phi, &sn, &cs);
+    return make_float2(cs, sn);
+}
+
 // out[k][m] = fd[k][m] - ic[m] * sum_p (td[k-1][p] + td[k+1][p]) W_M^{p m}     (receiver_kernel_cc.cc:274-299)
-__device__ void cancel_rows(cf* dst, const cf* td, const cf* fd, const DevicePlan& p)
+template <class Mx>
+__device__ __forceinline__ void cancel_rows(const Mx& mx, cf* dst, const cf* td, const cf* fd, const DevicePlan& p)
 {
     const int M = p.M, K = p.K;
-    paired_dft<false>(K, M, p.wM,
+    paired_dft<false>(mx, K, M, p.wM,
                       [&](int k, int q) { return cadd(td[(k == 0 ? K - 1 : k - 1) * M + q], td[(k == K - 1 ? 0 : k + 1) * M + q]); },
                       [&](int k, int m, const DftPair& acc) {
                           const int m2 = (m == 0) ? 0 : M - m;
@@ -286,7 +436,7 @@ __device__ void cancel_rows(cf* dst, const cf* td, const cf* fd, const DevicePla
 }
 
 // resource demapper in the store stage: active subcarriers only, mapper order (resource_mapper_kernel_cc.cc:91-106,136-163)
-__device__ void emit_demapped(cf* o, const cf* tile, const RxIo& io, int K, int M)
+__device__ __forceinline__ void emit_demapped(cf* o, const cf* tile, const RxIo& io, int K, int M)
 {
     for (int idx = threadIdx.x; idx < K * M; idx += GT) {
         const int k = idx / M, m = idx - k * M;
@@ -306,13 +456,22 @@ struct TileArgs {
     cf* gtiles;
     int64_t tile_elems;
     int64_t blk0;
+    int xs_off, xs_rtc;            // matrix-core transforms: byte offset of the operand scratch in the dynamic LDS region, row groups it holds (0: vector ALU)
 };
 
-template <bool GLOBAL>
-__global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan pg, TxParams tx, int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ in)
+template <bool MX>
+__device__ __forceinline__ auto mx_of(const DevicePlan& p, const TileArgs& ta, unsigned char* smem)
+{
+    if constexpr (MX) return MxDft{ p.dftA, reinterpret_cast<float*>(smem + ta.xs_off), ta.xs_rtc, p.dft_mt, p.dft_ks };
+    else return NoMx{};
+}
+
+template <bool GLOBAL, bool MX>
+__global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_modulate(DevicePlan pg, TxParams tx, int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ in)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevicePlan p = stage_tables(pg, smem, tab_off);
+    const auto mx = mx_of<MX>(p, ta, smem);
     cf* t0;
     if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem);
     cf* t1 = t0 + p.N;
@@ -324,10 +483,10 @@ __global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan pg, TxParams
     if (tx.mapped) {                                               // resource mapper fused into the load (gfdm_tx.h)
         for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = tx_symbol(tx, x, M, idx / M, idx % M);
     } else {
-        for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
+        stream_in(t1, x, N);
     }
     __syncthreads();
-    row_dft<false>(t0, t1, K, M, M, 1, p.wM, 1.f);                 // D_k = FFT_M(d_k)                 :109-110
+    row_dft<false>(mx, t0, t1, K, M, M, 1, p.wM, 1.f);                 // D_k = FFT_M(d_k)                 :109-110
     __syncthreads();
     // gather form of the filter + overlap-add scatter (:116-132):
     //   Y[j][m] = sum_i D[(j - i + L/2) mod K][m] * taps[((i + L/2) % L) M + m],  m < part_len
@@ -347,13 +506,14 @@ __global__ __launch_bounds__(GT) void k_generic_modulate(DevicePlan pg, TxParams
     cf* z = col_fft<true>(t1, t0, p);                              // K-point inverse over j
     cf* u = (z == t1) ? t0 : t1;
     DivStep qx(threadIdx.x, GT, M);
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < N; idx += GT, qx.next()) {   // twiddle conj(W_N^{q m})
         u[idx] = cmulj(z[idx], p.wN[qx.q * qx.r]);
     }
     __syncthreads();
     // x[K p + q] = (1/N) sum_m u[q][m] conj(W_M^{p m});  q fastest so the global store is coalesced   :137-140
     const float scale = 1.f / (float)N;
-    paired_dft<true>(K, M, p.wM, [&](int q, int m) { return u[q * M + m]; },
+    paired_dft<true>(mx, K, M, p.wM, [&](int q, int m) { return u[q * M + m]; },
                      [&](int q, int pp, const DftPair& acc) {                    // time slots pp and M - pp from one pass
                          const int pp2 = (pp == 0) ? 0 : M - pp;
                          const cf ya = acc.with_conj(), yb = acc.with_root();    // inverse transform: conj(W_M^{p m}) for pp, the root itself for M - pp
@@ -377,13 +537,14 @@ __global__ __launch_bounds__(GT) void k_add_frame(DevicePlan p, TxParams tx, con
     tx_store_preamble(tx, blockIdx.x, threadIdx.x, GT);
 }
 
-template <bool GLOBAL>
-__global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams ic, EstPlan est, int eq_source, int ntiles, int mode, int s_in_global,
+template <bool GLOBAL, bool MX>
+__global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_receive(DevicePlan pg, IcParams ic, EstPlan est, int eq_source, int ntiles, int mode, int s_in_global,
                                                         int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ in,
                                                         const cf* __restrict__ f_eq)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevicePlan p = stage_tables(pg, smem, tab_off);
+    const auto mx = mx_of<MX>(p, ta, smem);
     float* red = reinterpret_cast<float*>(smem);
     cf* t0;
     if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem + RED_BYTES);
@@ -404,10 +565,10 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams 
         __syncthreads();
     }
 
-    for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = x[idx];
+    stream_in(t1, x, N);
     __syncthreads();
     // A[q][m] = W_N^{q m} * sum_p x[K p + q] W_M^{p m}
-    paired_dft<false>(K, M, p.wM, [&](int q, int pp) { return t1[K * pp + q]; },       // outputs m and M - m from one pass (DftPair)
+    paired_dft<false>(mx, K, M, p.wM, [&](int q, int pp) { return t1[K * pp + q]; },       // outputs m and M - m from one pass (DftPair)
                       [&](int q, int m, const DftPair& acc) {
                           const int m2 = (m == 0) ? 0 : M - m;
                           t0[q * M + m] = cmul(acc.with_root(), p.wN[q * m]);
@@ -417,7 +578,7 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams 
     cf* X = col_fft<false>(t0, t1, p);                             // X[j][m] = FFT_N(x)[M j + m]       :304-305
     cf* U = (X == t0) ? t1 : t0;
     if (eq) {                                                      // one-tap equaliser                 :315-316
-        for (int idx = threadIdx.x; idx < N; idx += GT) X[idx] = cdiv(X[idx], eq[idx]);
+        stream_in(X, eq, N, [&](cf e, int idx) { return cdiv(X[idx], e); });
         __syncthreads();
     } else if (eq_source == EQ_PREAMBLE) {                         // same, the estimate interpolated on the fly
         for (int idx = threadIdx.x; idx < N; idx += GT) X[idx] = cdiv(X[idx], est_frame_bin<0>(filt, idx, est));
@@ -443,9 +604,9 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams 
     const float invM = 1.f / (float)M;
     if (mode == RX_DEMOD || ic.ic_iter <= 0) {
         if (!demap) {
-            row_dft<true>(o, U, K, M, M, 1, p.wM, invM);          // d = IFFT_M(S_k) / M                :211-225
+            row_dft<true>(mx, o, U, K, M, M, 1, p.wM, invM);          // d = IFFT_M(S_k) / M                :211-225
         } else {
-            row_dft<true>(X, U, K, M, M, 1, p.wM, invM);
+            row_dft<true>(mx, X, U, K, M, M, 1, p.wM, invM);
             __syncthreads();
             emit_demapped(o, X, ic.io, K, M);
         }
@@ -456,8 +617,34 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams 
     // and the M-tap circular kernel g = IDFT_M(ic) / M (p.icg): one table-driven pass per round instead of two, S is not needed
     // again (a rotation of S by the phase compensation is the same rotation of d0).
     cf* D = X;
-    row_dft<true>(D, U, K, M, M, 1, p.wM, invM);
+    row_dft<true>(mx, D, U, K, M, M, 1, p.wM, invM);
     __syncthreads();
+    if constexpr (MX) {
+        // With the transforms on the matrix cores the rounds keep the reference's own form, S' = S - ic (.) DFT_M(nb), d = IDFT_M(S') / M: two constant-
+        // matrix products per round instead of the O(M^2) convolution on the vector ALU.  S stays in its tile, S' goes to the third one (or the output block).
+        cf* S = U;
+        cf* V = s_in_global ? o : t2;
+        for (int j = 0; j < ic.ic_iter; ++j) {
+            if (ic.do_phase_compensation > 0 && j == 0) {
+                const cf rot = phase_rotation(D, ic, red, M);
+                for (int idx = threadIdx.x; idx < N; idx += GT) S[idx] = cmul(S[idx], rot);     // adv:63-70: the rotation of S persists
+                __syncthreads();
+            }
+            {
+                DivStep dx(threadIdx.x, GT, M);
+                for (int idx = threadIdx.x; idx < N; idx += GT, dx.next())
+                    D[idx] = ic.active[dx.q] ? decide(D[idx], ic) : make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+            cancel_rows(mx, V, D, S, p);
+            __syncthreads();
+            const bool last = (j == ic.ic_iter - 1);
+            row_dft<true>(mx, (last && !demap) ? o : D, V, K, M, M, 1, p.wM, invM);
+            __syncthreads();
+            if (last && demap) emit_demapped(o, D, ic.io, K, M);
+        }
+        return;
+    }
     cf* D0 = U;
     cf* V = t2;
     if (s_in_global) {                                            // third tile does not fit: d0 lives in the output block
@@ -467,24 +654,8 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams 
     for (int idx = threadIdx.x; idx < N; idx += GT) D0[idx] = D[idx];
     __syncthreads();
     for (int j = 0; j < ic.ic_iter; ++j) {                        // perform_ic_iterations            adv:56-76
-        if (ic.do_phase_compensation > 0 && j == 0) {              // calculate_phase_offset           adv:78-91
-            float acc = 0.f;
-            for (int idx = threadIdx.x; idx < ic.n_active * M; idx += GT) {
-                const int a = idx / M, m = idx - a * M;
-                const cf v = D[ic.smap[a] * M + m];
-                const cf d = decide(v, ic);
-                acc += atan2f(d.y, d.x) - atan2f(v.y, v.x);
-            }
-            red[threadIdx.x] = acc;
-            __syncthreads();
-            for (int s = GT / 2; s > 0; s >>= 1) {
-                if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-                __syncthreads();
-            }
-            const float phi = red[0] / (float)(ic.n_active * M);
-            float sn, cs;
-            sincosf(phi, &sn, &cs);
-            const cf rot = make_float2(cs, sn);
+        if (ic.do_phase_compensation > 0 && j == 0) {
+            const cf rot = phase_rotation(D, ic, red, M);
             for (int idx = threadIdx.x; idx < N; idx += GT) D0[idx] = cmul(D0[idx], rot);   // rotating S rotates d0; persists  adv:63-70
             __syncthreads();
         }
@@ -540,33 +711,35 @@ __global__ __launch_bounds__(GT) void k_generic_receive(DevicePlan pg, IcParams 
     }
 }
 
-template <bool GLOBAL>
-__global__ __launch_bounds__(GT) void k_generic_to_td(DevicePlan pg, int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ in)
+template <bool GLOBAL, bool MX>
+__global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_to_td(DevicePlan pg, int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ in)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevicePlan p = stage_tables(pg, smem, tab_off);
+    const auto mx = mx_of<MX>(p, ta, smem);
     cf* t0;
     if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem);
     const int64_t blk = ta.blk0 + blockIdx.x;
     const cf* x = in + blk * p.N;
-    for (int idx = threadIdx.x; idx < p.N; idx += GT) t0[idx] = x[idx];
+    stream_in(t0, x, p.N);
     __syncthreads();
-    row_dft<true>(out + blk * p.N, t0, p.K, p.M, p.M, 1, p.wM, 1.f / (float)p.M);
+    row_dft<true>(mx, out + blk * p.N, t0, p.K, p.M, p.M, 1, p.wM, 1.f / (float)p.M);
 }
 
-template <bool GLOBAL>
-__global__ __launch_bounds__(GT) void k_generic_cancel(DevicePlan pg, int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ td,
+template <bool GLOBAL, bool MX>
+__global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_cancel(DevicePlan pg, int tab_off, TileArgs ta, cf* __restrict__ out, const cf* __restrict__ td,
                                                        const cf* __restrict__ fd)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevicePlan p = stage_tables(pg, smem, tab_off);
+    const auto mx = mx_of<MX>(p, ta, smem);
     cf* t0;
     if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem);
     const int64_t blk = ta.blk0 + blockIdx.x;
     const cf* x = td + blk * p.N;
-    for (int idx = threadIdx.x; idx < p.N; idx += GT) t0[idx] = x[idx];
+    stream_in(t0, x, p.N);
     __syncthreads();
-    cancel_rows(out + blk * p.N, t0, fd + blk * p.N, p);
+    cancel_rows(mx, out + blk * p.N, t0, fd + blk * p.N, p);
 }
 
 
@@ -691,6 +864,39 @@ bool generic_supports(int M, int K, bool one_tile)
 
 namespace {
 
+// LDS scratch of the matrix-core timeslot transforms (mx_dft), behind everything else a kernel keeps in LDS: 1024 KS bytes per group of 16 rows
+// (four planes of [4 KS][16] floats).  As many row groups as do not lower the number of workgroups a CU holds; rtc = 0: the vector-ALU
+// instantiation of the kernel -- no table in the plan, not even one group fits, or (unless the handle asks for the form wherever it fits) the form
+// would not pay: measured, it wins where the 16 x 16 x 4 operand tiles are well filled (M = 127: 64 output pairs x 64 sample pairs = 4 x 16 full
+// tiles; M = 33: 17 x 17 in 32 x 20), the block has a unit of work for each of its four wavefronts, and the scratch leaves the CU at least
+// two workgroups (the kernels are latency-bound: workgroups per CU decide) -- K=16 M=127 modulate 155 -> 130 us, MF demod 185 -> 137 us per
+// 4096 blocks; K=61 M=33 147 -> 180 us and K=37 M=127 (one workgroup per CU with the scratch) 350 -> 400 us, which therefore stay on the vector ALU.
+struct MxLds {
+    int off, rtc;
+    size_t total;
+};
+MxLds mx_lds(const DevicePlan& p, size_t used)
+{
+    MxLds r{ 0, 0, used };
+    if (!p.dftA) return r;
+    const size_t per_rt = (size_t)1024 * (size_t)p.dft_ks, off = (used + 255) & ~(size_t)255;
+    if (off + per_rt > LDS_MAX) return r;
+    const int RT = (p.K + 15) / 16;
+    auto groups = [&](size_t bytes) { return std::min<size_t>(8, LDS_MAX / bytes); };
+    if (!p.dft_always) {
+        const int H = p.M / 2 + 1, KD = (p.M - 1) / 2 + 1 + ((p.M & 1) == 0 ? 1 : 0);
+        const double fill = (double)H * KD * p.K / ((double)(16 * p.dft_mt) * (4 * p.dft_ks) * (16 * RT));
+        if (fill < 0.7 || p.dft_mt * RT < GT / 64) return r;
+        if (groups(off + per_rt) < 2 && groups(off + per_rt) < groups(used)) return r;
+    }
+    int rtc = 1;
+    while (rtc < RT && groups(off + (size_t)(rtc + 1) * per_rt) == groups(off + per_rt)) ++rtc;
+    r.off = (int)off;
+    r.rtc = rtc;
+    r.total = off + (size_t)rtc * per_rt;
+    return r;
+}
+
 // scratch slices for a launch of the GLOBAL kernels: at most ~256 MiB, so a long batch goes down in chunks; allocated and freed in
 // stream order (no handle state: calls on different streams do not share it)
 struct Scratch {
@@ -715,18 +921,23 @@ hipError_t launch_generic_modulate(const DevicePlan& p, const TxParams& tx, cf* 
     if (nblocks <= 0) return hipSuccess;
     const size_t tab = generic_lds_bytes(p.N, 2), lds = tab + table_bytes(p);
     if (lds <= LDS_MAX) {
-        hipError_t e = allow_lds(k_generic_modulate<false>, lds);
+        const MxLds mx = mx_lds(p, lds);
+        auto kern = mx.rtc ? k_generic_modulate<false, true> : k_generic_modulate<false, false>;
+        hipError_t e = allow_lds(kern, mx.total);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_generic_modulate<false>, dim3((unsigned)nblocks), dim3(GT), lds, s, p, tx, (int)tab, TileArgs{ nullptr, 0, 0 }, out, in);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, tx, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc }, out, in);
         return hipGetLastError();
     }
     Scratch sc;
     const int64_t tile_elems = 2 * (int64_t)p.N;
     hipError_t e = sc.open(tile_elems, nblocks, s);
     if (e != hipSuccess) return e;
+    const MxLds mx = mx_lds(p, table_bytes(p));
+    auto kern = mx.rtc ? k_generic_modulate<true, true> : k_generic_modulate<true, false>;
+    if ((e = allow_lds(kern, mx.total)) != hipSuccess) return e;
     for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
         const int64_t n = std::min(sc.chunk, nblocks - b0);
-        hipLaunchKernelGGL(k_generic_modulate<true>, dim3((unsigned)n), dim3(GT), table_bytes(p), s, p, tx, 0, TileArgs{ sc.base, tile_elems, b0 }, out, in);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, tx, 0, TileArgs{ sc.base, tile_elems, b0, mx.off, mx.rtc }, out, in);
         e = hipGetLastError();
     }
     const hipError_t e2 = sc.close();
@@ -756,10 +967,12 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const
         }
         if (!(s_in_global && ic.io.demap)) {                               // (a demapped output block is too small to park S in: GLOBAL below)
             const size_t tab = (generic_lds_bytes(p.N, ntiles) + extra + 15) & ~(size_t)15, lds = tab + table_bytes(p);
-            hipError_t e = allow_lds(k_generic_receive<false>, lds);
+            const MxLds mx = mx_lds(p, lds);
+            auto kern = mx.rtc ? k_generic_receive<false, true> : k_generic_receive<false, false>;
+            hipError_t e = allow_lds(kern, mx.total);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_generic_receive<false>, dim3((unsigned)nblocks), dim3(GT), lds, s, p, ic, est ? *est : kNoEst, eq_source, ntiles, mode,
-                               s_in_global, (int)tab, TileArgs{ nullptr, 0, 0 }, out, in, f_eq);
+            hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, ic, est ? *est : kNoEst, eq_source, ntiles, mode,
+                               s_in_global, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc }, out, in, f_eq);
             return hipGetLastError();
         }
     }
@@ -769,10 +982,13 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const
     hipError_t e = sc.open(tile_elems, nblocks, s);
     if (e != hipSuccess) return e;
     const size_t tab = (RED_BYTES + 15) & ~(size_t)15;
+    const MxLds mx = mx_lds(p, tab + table_bytes(p));
+    auto kern = mx.rtc ? k_generic_receive<true, true> : k_generic_receive<true, false>;
+    if ((e = allow_lds(kern, mx.total)) != hipSuccess) return e;
     for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
         const int64_t n = std::min(sc.chunk, nblocks - b0);
-        hipLaunchKernelGGL(k_generic_receive<true>, dim3((unsigned)n), dim3(GT), tab + table_bytes(p), s, p, ic, est ? *est : kNoEst, eq_source, ntiles,
-                           mode, 0, (int)tab, TileArgs{ sc.base, tile_elems, b0 }, out, in, f_eq);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, ic, est ? *est : kNoEst, eq_source, ntiles,
+                           mode, 0, (int)tab, TileArgs{ sc.base, tile_elems, b0, mx.off, mx.rtc }, out, in, f_eq);
         e = hipGetLastError();
     }
     const hipError_t e2 = sc.close();
@@ -784,17 +1000,22 @@ hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int6
     if (nblocks <= 0) return hipSuccess;
     const size_t tab = generic_lds_bytes(p.N, 1), lds = tab + table_bytes(p);
     if (lds <= LDS_MAX) {
-        hipError_t e = allow_lds(k_generic_to_td<false>, lds);
+        const MxLds mx = mx_lds(p, lds);
+        auto kern = mx.rtc ? k_generic_to_td<false, true> : k_generic_to_td<false, false>;
+        hipError_t e = allow_lds(kern, mx.total);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_generic_to_td<false>, dim3((unsigned)nblocks), dim3(GT), lds, s, p, (int)tab, TileArgs{ nullptr, 0, 0 }, out, in);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc }, out, in);
         return hipGetLastError();
     }
     Scratch sc;
     hipError_t e = sc.open(p.N, nblocks, s);
     if (e != hipSuccess) return e;
+    const MxLds mx = mx_lds(p, table_bytes(p));
+    auto kern = mx.rtc ? k_generic_to_td<true, true> : k_generic_to_td<true, false>;
+    if ((e = allow_lds(kern, mx.total)) != hipSuccess) return e;
     for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
         const int64_t n = std::min(sc.chunk, nblocks - b0);
-        hipLaunchKernelGGL(k_generic_to_td<true>, dim3((unsigned)n), dim3(GT), table_bytes(p), s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0 }, out, in);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0, mx.off, mx.rtc }, out, in);
         e = hipGetLastError();
     }
     const hipError_t e2 = sc.close();
@@ -806,17 +1027,22 @@ hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, con
     if (nblocks <= 0) return hipSuccess;
     const size_t tab = generic_lds_bytes(p.N, 1), lds = tab + table_bytes(p);
     if (lds <= LDS_MAX) {
-        hipError_t e = allow_lds(k_generic_cancel<false>, lds);
+        const MxLds mx = mx_lds(p, lds);
+        auto kern = mx.rtc ? k_generic_cancel<false, true> : k_generic_cancel<false, false>;
+        hipError_t e = allow_lds(kern, mx.total);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_generic_cancel<false>, dim3((unsigned)nblocks), dim3(GT), lds, s, p, (int)tab, TileArgs{ nullptr, 0, 0 }, out, td, fd);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc }, out, td, fd);
         return hipGetLastError();
     }
     Scratch sc;
     hipError_t e = sc.open(p.N, nblocks, s);
     if (e != hipSuccess) return e;
+    const MxLds mx = mx_lds(p, table_bytes(p));
+    auto kern = mx.rtc ? k_generic_cancel<true, true> : k_generic_cancel<true, false>;
+    if ((e = allow_lds(kern, mx.total)) != hipSuccess) return e;
     for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
         const int64_t n = std::min(sc.chunk, nblocks - b0);
-        hipLaunchKernelGGL(k_generic_cancel<true>, dim3((unsigned)n), dim3(GT), table_bytes(p), s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0 }, out, td, fd);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0, mx.off, mx.rtc }, out, td, fd);
         e = hipGetLastError();
     }
     const hipError_t e2 = sc.close();

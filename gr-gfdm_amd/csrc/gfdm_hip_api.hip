@@ -59,6 +59,7 @@ std::atomic<int> g_jit{ 3 };
 // gfdm_hip_set_ic_matrix_cores: 0 = handles created meanwhile run every cancellation round on the vector ALU, 1 (default) = matrix cores where
 // they are the faster form (gfdm_rowgeom.h ic_mfma_preferred), 2 = matrix cores wherever the form applies
 std::atomic<int> g_ic_mfma{ 1 };
+std::atomic<int> g_dft_mfma{ 1 };
 
 struct Plan {
     int device = 0;
@@ -256,6 +257,35 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
         ic_sig = bits;
     }
 
+    // Matrix-core form of the generic family's timeslot transforms (mx_dft, gfdm_generic.hip): the paired DFT
+    //   Q1 = C a.x, Q2 = C a.y, Q3 = S b.x, Q4 = S b.y   with a = v_p + v_{M-p}, b = v_p - v_{M-p}, C[m][p] = Re W_M^{m p}, S[m][p] = Im W_M^{m p}
+    // as products of the CONSTANT matrices C, S (rows: outputs m <= M/2, columns: p = 0 (C = 1: the sample v_0 itself), the pairs p = 1..(M-1)/2,
+    // the middle sample of an even M) with the block's samples.  A operand of v_mfma_f32_16x16x4_f32: lane l holds A[row l & 15][k = l >> 4].
+    size_t dftA_off = 0;
+    int dft_mt = 0, dft_ks = 0;
+    if (g_dft_mfma.load() && M >= gfdm::MX_DFT_MIN_M) {
+        const double two_pi = 6.283185307179586476925286766559;
+        const int H = M / 2 + 1, HP = (M - 1) / 2, KD = HP + 1 + ((M & 1) == 0 ? 1 : 0);
+        dft_mt = (H + 15) / 16;
+        dft_ks = (KD + 3) / 4;
+        if (tables.size() & 1) tables.push_back(make_float2(0.f, 0.f));
+        dftA_off = tables.size();
+        std::vector<float> A((size_t)dft_mt * dft_ks * 128, 0.f);
+        for (int mt = 0; mt < dft_mt; ++mt)
+            for (int ks = 0; ks < dft_ks; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int m = 16 * mt + (lane & 15), kk = 4 * ks + (lane >> 4);
+                    if (m >= H || kk >= KD) continue;
+                    const int pidx = (kk <= HP) ? kk : M / 2;
+                    const double a = -two_pi * (double)(((int64_t)m * pidx) % M) / (double)M;
+                    float* dst = A.data() + ((size_t)(mt * dft_ks + ks) * 2) * 64 + lane;
+                    dst[0] = (float)std::cos(a);
+                    dst[64] = (kk >= 1 && kk <= HP) ? (float)std::sin(a) : 0.f;
+                }
+        const cf* packed = reinterpret_cast<const cf*>(A.data());
+        tables.insert(tables.end(), packed, packed + A.size() / 2);
+    }
+
     DeviceGuard guard(device);
     if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
     HIP_TRY(hipMalloc(&pl.d_tables, tables.size() * sizeof(cf)));
@@ -278,6 +308,10 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     dp.wK = dp.wM + M;
     dp.wN = dp.wK + K;
     pl.d_twT = pl.d_tables + twT_off;
+    dp.dftA = dft_mt ? reinterpret_cast<const float*>(pl.d_tables + dftA_off) : nullptr;
+    dp.dft_mt = dft_mt;
+    dp.dft_ks = dft_ks;
+    dp.dft_always = g_dft_mfma.load() == 2 ? 1 : 0;
     // kernel family: row-lane where the shape is instantiated, else the generic LDS family.  Only the explicit test hook
     // gfdm_hip_force_generic_family_for_testing changes that; no environment variable does.
     pl.family = gfdm::FAMILY_GENERIC;
@@ -594,6 +628,11 @@ int gfdm_hip_precompile(int timeslots, int subcarriers, int overlap, unsigned pa
 int gfdm_hip_set_ic_matrix_cores(int mode)
 {
     return g_ic_mfma.exchange(mode < 0 ? 0 : mode > 2 ? 2 : mode);
+}
+
+int gfdm_hip_set_dft_matrix_cores(int mode)
+{
+    return g_dft_mfma.exchange(mode < 0 ? 0 : mode > 2 ? 2 : mode);
 }
 
 int gfdm_hip_jit_build_for_testing(int timeslots, int subcarriers, int overlap, int part)

@@ -32,6 +32,11 @@ struct DevicePlan {
     const cf* wM;       // [M]   exp(-2 pi j p / M)
     const cf* wK;       // [K]   exp(-2 pi j q / K)
     const cf* wN;       // [N]   exp(-2 pi j r / N)
+    // matrix-core form of the generic family's timeslot transforms (gfdm_generic.hip, mx_dft; M >= 32): the cosine / sine matrices of the paired
+    // DFT as A operands of v_mfma_f32_16x16x4_f32, [dft_mt output tiles][dft_ks k-steps][2: cos, sin][64 lanes]; nullptr = vector-ALU form
+    const float* dftA;
+    int dft_mt, dft_ks;
+    int dft_always;     // 1: wherever the operand scratch fits LDS (gfdm_hip_set_dft_matrix_cores(2)), 0: only where that form is the faster one
 };
 
 // Where the receiver finds its samples and how it emits its symbols: the cyclic-prefix removal
@@ -67,6 +72,9 @@ inline bool ic_mfma_applies(const DevicePlan& p, const IcParams& ic)
 {
     return p.ic_sig != 0 && p.icA != nullptr && ic.decision == 1 && ic.do_phase_compensation <= 0;
 }
+
+// from this many timeslots on the generic family's timeslot transforms run on the matrix cores (DevicePlan::dftA)
+constexpr int MX_DFT_MIN_M = 32;
 
 enum RxMode {
     RX_FD = 0,        // fft_[equalize_]filter_downsample: out = S

@@ -52,6 +52,7 @@ def lib():
         "gfdm_hip_set_jit": (i32, [i32]),
         "gfdm_hip_precompile": (i32, [i32, i32, i32, ctypes.c_uint]),
         "gfdm_hip_set_ic_matrix_cores": (i32, [i32]),
+        "gfdm_hip_set_dft_matrix_cores": (i32, [i32]),
         "gfdm_hip_jit_build_for_testing": (i32, [i32, i32, i32, i32]),
         "gfdm_hip_version": (cp, []),
         "gfdm_hip_modulator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
@@ -245,6 +246,13 @@ def set_ic_matrix_cores(mode):
     only, 1 / True (default) matrix cores where they are the faster form (subcarriers >= 128), 2 matrix cores wherever the form applies.
     Returns the previous mode."""
     return lib().gfdm_hip_set_ic_matrix_cores(int(mode))
+
+
+def set_dft_matrix_cores(mode):
+    """gfdm_hip_set_dft_matrix_cores: where the generic kernel family of handles created afterwards runs its timeslot transforms on the
+    matrix cores (f32 MFMA; from 32 timeslots on) -- 0 / False never, 1 / True (default) where that is the faster form, 2 wherever the form
+    fits.  Returns the previous mode."""
+    return lib().gfdm_hip_set_dft_matrix_cores(int(mode))
 
 
 class _Kernel:

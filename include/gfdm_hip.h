@@ -93,6 +93,13 @@ int gfdm_hip_precompile(int timeslots, int subcarriers, int overlap, unsigned pa
  * created afterwards (returns the previous mode): 0 = vector ALU only (f32 throughout), 1 (default) = matrix cores where they are the
  * faster form (blocks of two or more wavefronts: subcarriers >= 128), 2 = matrix cores wherever the form applies. */
 int gfdm_hip_set_ic_matrix_cores(int mode);
+/* The timeslot-axis transforms of the generic kernel family (shapes outside the tuned row-lane families: more than 48 timeslots, a number of
+ * subcarriers with a prime factor above 31 or above 1024; lib/modulator_kernel_cc.cc:109-110,137-140, lib/receiver_kernel_cc.cc:211-225,
+ * 274-299, 304-305) are direct sums; from 32 timeslots on they can run on the matrix cores as products of the constant cosine / sine matrices
+ * with the block's samples (v_mfma_f32_16x16x4_f32: f32 operands, f32 sums -- no reduced precision).  Mode of the handles created afterwards
+ * (returns the previous mode): 0 = vector ALU only, 1 (default) = matrix cores where they are the faster form (the 16 x 16 x 4 operand tiles
+ * well filled, at least four of them per block, and the operand scratch does not cost the CU its second workgroup), 2 = wherever the form fits. */
+int gfdm_hip_set_dft_matrix_cores(int mode);
 /* TEST HOOK: compile (or find in the disk cache) part 0..4 (receive, receive + IC, preamble-equalised receive, modulate, estimator) of
  * the row-lane kernels for a shape through hiprtc WITHOUT loading it --
  * needs no GPU, so the CPU-side tests can check that the embedded kernel sources build. */

@@ -9,6 +9,7 @@ from gfdm_amd.filters import get_frequency_domain_filter
 K, M, L, B = (int(x) for x in sys.argv[1:5]); alpha = float(sys.argv[5]) if len(sys.argv) > 5 else 0.2
 N = K * M; dev = torch.device("cuda:0")
 taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+if "GFDM_DFT_MX" in os.environ: gfdm_amd.set_dft_matrix_cores(int(os.environ["GFDM_DFT_MX"]))      # generic family: timeslot transforms on the matrix cores (default) / vector ALU
 mod = gfdm_amd.Modulator(M, K, L, taps); dem = gfdm_amd.Demodulator(M, K, L, taps)
 qpsk = np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) / np.sqrt(2)
 adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, qpsk)

@@ -674,6 +674,50 @@ def test_generic_family_any_subcarrier_count(M, K, L):
         assert rel_err(adv.demodulate_equalize(xe, feq)[keep], ref[keep]) < TOL
 
 
+@pytest.mark.parametrize("M,K,L", [(127, 16, 2), (32, 16, 2), (33, 20, 2), (48, 6, 3), (63, 37, 2), (64, 8, 2), (100, 16, 4), (127, 40, 2), (255, 3, 2),
+                                   (35, 74, 2)])
+def test_generic_family_matrix_core_timeslot_transforms(M, K, L):
+    """From 32 timeslots on the generic family runs its timeslot transforms on the matrix cores (mx_dft, gfdm_generic.hip: constant cosine / sine
+    matrices x the block's sample pairs, v_mfma_f32_16x16x4_f32 -- f32 operands and sums).  Modulator, MF / ZF receiver, IC receiver and the stand-alone
+    transform_subcarriers_to_td / cancel_sc_interference against the float64 oracle, and the vector-ALU form of the same handle kind beside it
+    (odd, even, prime M; row counts that are not a multiple of the 16-row operand group; several row groups per LDS chunk and one)."""
+    import gfdm_amd
+    rng = np.random.default_rng(7 * K + 3 * M + L)
+    N, B = M * K, 4
+    taps = get_frequency_domain_filter("rrc", 0.35, M, K, L)
+    nt = R.normalize_taps(taps, M)
+    sym = qpsk(rng, (B, N))
+    x = R.modulate(sym, nt, M, K, L)
+    feq = np.fft.fft(np.array([1, .25 - .2j, .1j]), N)[None, :] * np.ones((B, 1))
+    xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
+    ref, st = R.advanced_receive(xe, nt, M, K, L, np.arange(K), R.qpsk_points(), 2, f_eq=feq, kind="qpsk", return_stages=True)
+    keep = guarded(st, np.arange(K), K, M)
+    outs = {}
+    for on in (2, 0):                                            # 2: the matrix-core form wherever it fits, also where mode 1 would not choose it
+        prev = gfdm_amd.set_dft_matrix_cores(on)
+        try:
+            with gfdm_amd.generic_family_for_testing():
+                mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+                adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+        finally:
+            gfdm_amd.set_dft_matrix_cores(prev)
+        assert mod.kernel_name() == "generic_lds"
+        o = outs[on] = dict(mod=mod.modulate(sym), mf=dem.demodulate(x), zf=dem.demodulate_equalize(xe, feq), ic=adv.demodulate_equalize(xe, feq))
+        check_err("generic_mx%d_mod" % on, rel_err(o["mod"], x), TOL)
+        check_err("generic_mx%d_mf" % on, rel_err(o["mf"], R.demodulate(x, nt, M, K, L)), TOL)
+        check_err("generic_mx%d_zf" % on, rel_err(o["zf"], R.demodulate(xe, nt, M, K, L, feq)), TOL)
+        if keep.any():
+            check_err("generic_mx%d_ic" % on, rel_err(o["ic"][keep], ref[keep]), TOL)
+        fd = dem.fft_filter_downsample(x)
+        td = dem.transform_subcarriers_to_td(fd)
+        check_err("generic_mx%d_to_td" % on, rel_err(td, R.transform_subcarriers_to_td(R.fft_filter_downsample(x, nt, M, K, L), M, K)), TOL)
+        check_err("generic_mx%d_cancel" % on, rel_err(dem.cancel_sc_interference(sym, fd),
+                                                      R.cancel_sc_interference(sym, np.asarray(fd), R.ic_filter_taps(nt, M, L), M, K)), TOL)
+    # the two forms compute the same sums in a different order
+    assert rel_err(outs[2]["mod"], outs[0]["mod"]) < 2e-6
+    assert rel_err(outs[2]["mf"], outs[0]["mf"]) < 2e-6
+
+
 @pytest.mark.parametrize("M,K,L,alpha", [(7, 16, 2, 0.3), (13, 32, 4, 0.4), (11, 8, 2, 0.5), (27, 128, 2, 0.2), (6, 256, 2, 0.3), (28, 64, 2, 0.1), (5, 4, 8, 0.5),
                                          (10, 96, 2, 0.35), (21, 12, 2, 0.35), (9, 48, 4, 0.3), (7, 240, 2, 0.2), (15, 80, 2, 0.3), (9, 15, 2, 0.4), (3, 6, 2, 0.5),
                                          (4, 100, 2, 0.5), (5, 20, 6, 0.4), (9, 512, 2, 0.3), (15, 1024, 2, 0.2),
@@ -841,7 +885,7 @@ def test_handles_on_concurrent_host_threads():
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("M,K,L", [(15, 1040, 2), (49, 512, 2), (5, 4096, 4)])
+@pytest.mark.parametrize("M,K,L", [(15, 1040, 2), (49, 512, 2), (5, 4096, 4), (127, 100, 2)])
 def test_blocks_larger_than_the_lds(M, K, L):
     """Blocks whose tiles do not fit the 160 KiB of a CU (N > ~10 000: K = 1024 x M = 15 ...) run the generic kernels with their tiles
     in a global scratch buffer (K = 1024 itself is a row-lane shape: three wide passes): every entry point against the oracle, frames / demapper, the fused transmitter, and a batch long
