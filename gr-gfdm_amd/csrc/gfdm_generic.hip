@@ -23,6 +23,20 @@ namespace {
 constexpr int GT = 256;           // threads per workgroup
 constexpr int RED_BYTES = 1024;   // reduction scratch carved from the dynamic LDS region
 
+// Diagnostic build only (-DGFDM_STAMPS, scratch/stamps_generic.py): timestamps of the phase boundaries, one set per wavefront, written to a
+// side buffer that nothing else reads.  The product library is built without it.
+#ifdef GFDM_STAMPS
+__device__ unsigned long long* g_gstamp_buf = nullptr;
+#define GFDM_GSTAMP(slot)                                                                                        \
+    do {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                              \
+        if (g_gstamp_buf && (threadIdx.x & 63) == 0)                                                              \
+            g_gstamp_buf[((size_t)blockIdx.x * (GT / 64) + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define GFDM_GSTAMP(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ cf cmulj(cf a, cf b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a * conj(b)
 __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -67,18 +81,25 @@ __device__ __forceinline__ DevicePlan stage_tables(const DevicePlan& p, unsigned
     return q;                                   // the caller's first __syncthreads() publishes the tables
 }
 
-// Global -> LDS copy of a block with FOUR loads of a thread in flight (a plain `dst[i] = src[i]` loop of unknown length waits for every load before
+// Global -> LDS copy of a block with up to EIGHT loads of a thread in flight (a plain `dst[i] = src[i]` loop of unknown length waits for every load before
 // it issues the next one: eight DRAM round trips per thread for a 2000-sample block).  op(value, index) is applied on the way.
 template <class Op>
 __device__ __forceinline__ void stream_in(cf* dst, const cf* __restrict__ src, int n, Op op)
 {
     int idx = threadIdx.x;
+    for (; idx + 7 * GT < n; idx += 8 * GT) {
+        cf v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[idx + j * GT];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[idx + j * GT] = op(v[j], idx + j * GT);
+    }
     for (; idx + 3 * GT < n; idx += 4 * GT) {
-        const cf a = src[idx], b = src[idx + GT], c = src[idx + 2 * GT], d = src[idx + 3 * GT];
-        dst[idx] = op(a, idx);
-        dst[idx + GT] = op(b, idx + GT);
-        dst[idx + 2 * GT] = op(c, idx + 2 * GT);
-        dst[idx + 3 * GT] = op(d, idx + 3 * GT);
+        cf v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = src[idx + j * GT];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[idx + j * GT] = op(v[j], idx + j * GT);
     }
     for (; idx < n; idx += GT) dst[idx] = op(src[idx], idx);
 }
@@ -159,6 +180,15 @@ struct MxDft {
     const float* A;
     float* xs;
     int rtc, MT, KS;
+    int alias;             // 1: no scratch of its own -- a transform borrows the tile that is free at that point (`at`) and takes all row groups at once
+    // the transform of `rows` rows whose operands go to the free tile `tile` (alias form; else the scratch region as it is)
+    __device__ __forceinline__ MxDft at(cf* tile, int rows) const
+    {
+        MxDft m = *this;
+        if (alias) { m.xs = reinterpret_cast<float*>(tile); m.rtc = (rows + 15) / 16; }
+        return m;
+    }
+    __device__ __forceinline__ bool in_place() const { return alias != 0; }
 };
 
 typedef float mx_f4 __attribute__((ext_vector_type(4)));
@@ -244,7 +274,10 @@ __device__ __forceinline__ void mx_dft(const MxDft& mx, int rows, int M, Src src
 
 // kernels come in two instantiations: with the matrix-core transforms (an MxDft in hand) and without (NoMx: the vector-ALU loops; these do not
 // carry the accumulator registers of the other form, which would cost the small shapes their occupancy)
-struct NoMx {};
+struct NoMx {
+    __device__ __forceinline__ NoMx at(cf*, int) const { return NoMx{}; }
+    __device__ __forceinline__ bool in_place() const { return false; }
+};
 
 template <bool ROWFAST, class Src, class Fin>
 __device__ __forceinline__ void paired_dft(const MxDft& mx, int rows, int M, const cf* __restrict__, Src src, Fin fin)
@@ -457,12 +490,14 @@ struct TileArgs {
     int64_t tile_elems;
     int64_t blk0;
     int xs_off, xs_rtc;            // matrix-core transforms: byte offset of the operand scratch in the dynamic LDS region, row groups it holds (0: vector ALU)
+    int xs_alias;                  // ... or no scratch region: the operands go to whichever tile is free (MxDft::at); the LDS tiles are then tile_stride apart
+    int tile_stride;               // elements between the tiles in LDS (>= N: a tile must also hold the operands of a whole block)
 };
 
 template <bool MX>
 __device__ __forceinline__ auto mx_of(const DevicePlan& p, const TileArgs& ta, unsigned char* smem)
 {
-    if constexpr (MX) return MxDft{ p.dftA, reinterpret_cast<float*>(smem + ta.xs_off), ta.xs_rtc, p.dft_mt, p.dft_ks };
+    if constexpr (MX) return MxDft{ p.dftA, reinterpret_cast<float*>(smem + ta.xs_off), ta.xs_rtc, p.dft_mt, p.dft_ks, ta.xs_alias };
     else return NoMx{};
 }
 
@@ -474,11 +509,12 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_modulate(DevicePlan 
     const auto mx = mx_of<MX>(p, ta, smem);
     cf* t0;
     if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem);
-    cf* t1 = t0 + p.N;
     const int M = p.M, K = p.K, L = p.L, N = p.N;
+    cf* t1 = t0 + (GLOBAL ? N : ta.tile_stride);
     const int64_t blk = ta.blk0 + blockIdx.x;
     const cf* x = in + blk * (tx.mapped ? tx.nin : N);
     cf* o = out + blk * N;
+    GFDM_GSTAMP(0);
 
     if (tx.mapped) {                                               // resource mapper fused into the load (gfdm_tx.h)
         for (int idx = threadIdx.x; idx < N; idx += GT) t1[idx] = tx_symbol(tx, x, M, idx / M, idx % M);
@@ -486,8 +522,13 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_modulate(DevicePlan 
         stream_in(t1, x, N);
     }
     __syncthreads();
-    row_dft<false>(mx, t0, t1, K, M, M, 1, p.wM, 1.f);                 // D_k = FFT_M(d_k)                 :109-110
+    GFDM_GSTAMP(1);
+    // (matrix-core form without a scratch of its own: the operands go to the free tile t0, the spectra replace the samples in t1)
+    cf* D = mx.in_place() ? t1 : t0;
+    cf* Y = mx.in_place() ? t0 : t1;
+    row_dft<false>(mx.at(t0, K), D, t1, K, M, M, 1, p.wM, 1.f);       // D_k = FFT_M(d_k)                 :109-110
     __syncthreads();
+    GFDM_GSTAMP(2);
     // gather form of the filter + overlap-add scatter (:116-132):
     //   Y[j][m] = sum_i D[(j - i + L/2) mod K][m] * taps[((i + L/2) % L) M + m],  m < part_len
     DivStep jx(threadIdx.x, GT, M);
@@ -497,23 +538,26 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_modulate(DevicePlan 
         if (m < p.part_len) {
             for (int i = 0; i < L; ++i) {
                 const int k = ((j - i + L / 2) % K + K) % K;
-                acc = cfma(t0[k * M + m], p.taps[((i + L / 2) % L) * M + m], acc);
+                acc = cfma(D[k * M + m], p.taps[((i + L / 2) % L) * M + m], acc);
             }
         }
-        t1[idx] = acc;
+        Y[idx] = acc;
     }
     __syncthreads();
-    cf* z = col_fft<true>(t1, t0, p);                              // K-point inverse over j
-    cf* u = (z == t1) ? t0 : t1;
+    GFDM_GSTAMP(3);
+    cf* z = col_fft<true>(Y, D, p);                                // K-point inverse over j
+    GFDM_GSTAMP(4);
+    cf* u = (z == Y) ? D : Y;
     DivStep qx(threadIdx.x, GT, M);
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < N; idx += GT, qx.next()) {   // twiddle conj(W_N^{q m})
         u[idx] = cmulj(z[idx], p.wN[qx.q * qx.r]);
     }
     __syncthreads();
+    GFDM_GSTAMP(5);
     // x[K p + q] = (1/N) sum_m u[q][m] conj(W_M^{p m});  q fastest so the global store is coalesced   :137-140
     const float scale = 1.f / (float)N;
-    paired_dft<true>(mx, K, M, p.wM, [&](int q, int m) { return u[q * M + m]; },
+    paired_dft<true>(mx.at(z, K), K, M, p.wM, [&](int q, int m) { return u[q * M + m]; },
                      [&](int q, int pp, const DftPair& acc) {                    // time slots pp and M - pp from one pass
                          const int pp2 = (pp == 0) ? 0 : M - pp;
                          const cf ya = acc.with_conj(), yb = acc.with_root();    // inverse transform: conj(W_M^{p m}) for pp, the root itself for M - pp
@@ -527,6 +571,7 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_modulate(DevicePlan 
                          }
                      });
     if (tx.framed) tx_store_preamble(tx, blk, threadIdx.x, GT);
+    GFDM_GSTAMP(6);
 }
 
 // transmitter_kernel::add_frame on an already modulated block
@@ -548,17 +593,18 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_receive(DevicePlan p
     float* red = reinterpret_cast<float*>(smem);
     cf* t0;
     if constexpr (GLOBAL) t0 = ta.gtiles + (int64_t)blockIdx.x * ta.tile_elems; else t0 = reinterpret_cast<cf*>(smem + RED_BYTES);
-    cf* t1 = t0 + p.N;
-    cf* t2 = t1 + p.N;                                             // only valid when 3 tiles were requested
     const int M = p.M, K = p.K, L = p.L, N = p.N;
+    const int TS = GLOBAL ? N : ta.tile_stride;
+    cf* t1 = t0 + TS;
+    cf* t2 = t1 + TS;                                              // only valid when 3 tiles were requested
     const int64_t blk = ta.blk0 + blockIdx.x;
     const cf* x = in + blk * (int64_t)(ic.io.in_stride ? ic.io.in_stride : N) + ic.io.in_offset;   // frame -> block
     const bool demap = ic.io.demap && mode != RX_FD;
     cf* o = out + blk * (demap ? ic.io.nout : N);
     const cf* eq = (eq_source == EQ_VECTOR) ? f_eq + blk * N : nullptr;
-    cf* filt = t0 + (size_t)ntiles * N + K;                       // EQ_PREAMBLE: smoothed channel estimate, behind the tiles
+    cf* filt = t0 + (size_t)ntiles * TS + K;                      // EQ_PREAMBLE: smoothed channel estimate, behind the tiles
     if (eq_source == EQ_PREAMBLE) {                                // channel estimator in front, the tiles are its scratch
-        cf* bins = t0 + (size_t)ntiles * N;
+        cf* bins = t0 + (size_t)ntiles * TS;
         estimate_preamble_bins(est, f_eq + blk * (est.pre_stride ? est.pre_stride : 2 * K), t0, t1, bins);
         __syncthreads();
         for (int i = threadIdx.x; i < est.n_est; i += GT) filt[i] = est_filter_bin(bins, i, est);
@@ -568,15 +614,18 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_receive(DevicePlan p
     stream_in(t1, x, N);
     __syncthreads();
     // A[q][m] = W_N^{q m} * sum_p x[K p + q] W_M^{p m}
-    paired_dft<false>(mx, K, M, p.wM, [&](int q, int pp) { return t1[K * pp + q]; },       // outputs m and M - m from one pass (DftPair)
+    // (matrix-core form without a scratch of its own: the operands go to the free tile t0, the result replaces the samples in t1)
+    cf* A0 = mx.in_place() ? t1 : t0;
+    cf* A1 = mx.in_place() ? t0 : t1;
+    paired_dft<false>(mx.at(t0, K), K, M, p.wM, [&](int q, int pp) { return t1[K * pp + q]; },       // outputs m and M - m from one pass (DftPair)
                       [&](int q, int m, const DftPair& acc) {
                           const int m2 = (m == 0) ? 0 : M - m;
-                          t0[q * M + m] = cmul(acc.with_root(), p.wN[q * m]);
-                          if (m2 != m) t0[q * M + m2] = cmul(acc.with_conj(), p.wN[q * m2]);
+                          A0[q * M + m] = cmul(acc.with_root(), p.wN[q * m]);
+                          if (m2 != m) A0[q * M + m2] = cmul(acc.with_conj(), p.wN[q * m2]);
                       });
     __syncthreads();
-    cf* X = col_fft<false>(t0, t1, p);                             // X[j][m] = FFT_N(x)[M j + m]       :304-305
-    cf* U = (X == t0) ? t1 : t0;
+    cf* X = col_fft<false>(A0, A1, p);                             // X[j][m] = FFT_N(x)[M j + m]       :304-305
+    cf* U = (X == A0) ? A1 : A0;
     if (eq) {                                                      // one-tap equaliser                 :315-316
         stream_in(X, eq, N, [&](cf e, int idx) { return cdiv(X[idx], e); });
         __syncthreads();
@@ -604,11 +653,12 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_receive(DevicePlan p
     const float invM = 1.f / (float)M;
     if (mode == RX_DEMOD || ic.ic_iter <= 0) {
         if (!demap) {
-            row_dft<true>(mx, o, U, K, M, M, 1, p.wM, invM);          // d = IFFT_M(S_k) / M                :211-225
+            row_dft<true>(mx.at(X, K), o, U, K, M, M, 1, p.wM, invM);      // d = IFFT_M(S_k) / M                :211-225
         } else {
-            row_dft<true>(mx, X, U, K, M, M, 1, p.wM, invM);
+            cf* d = mx.in_place() ? U : X;                              // (X holds the operands then)
+            row_dft<true>(mx.at(X, K), d, U, K, M, M, 1, p.wM, invM);
             __syncthreads();
-            emit_demapped(o, X, ic.io, K, M);
+            emit_demapped(o, d, ic.io, K, M);
         }
         return;
     }
@@ -616,14 +666,15 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_receive(DevicePlan p
     // (receiver_kernel_cc.cc:274-299 + :211-225).  Both transforms are linear, so  d_new = d0 - g (*) nb  with d0 = IDFT_M(S) / M
     // and the M-tap circular kernel g = IDFT_M(ic) / M (p.icg): one table-driven pass per round instead of two, S is not needed
     // again (a rotation of S by the phase compensation is the same rotation of d0).
-    cf* D = X;
-    row_dft<true>(mx, D, U, K, M, M, 1, p.wM, invM);
+    cf* D = mx.in_place() ? t2 : X;                                // (in place: X takes the operands of every transform from here on)
+    row_dft<true>(mx.at(X, K), D, U, K, M, M, 1, p.wM, invM);
     __syncthreads();
     if constexpr (MX) {
         // With the transforms on the matrix cores the rounds keep the reference's own form, S' = S - ic (.) DFT_M(nb), d = IDFT_M(S') / M: two constant-
         // matrix products per round instead of the O(M^2) convolution on the vector ALU.  S stays in its tile, S' goes to the third one (or the output block).
         cf* S = U;
-        cf* V = s_in_global ? o : t2;
+        cf* V = mx.in_place() ? D : s_in_global ? o : t2;             // (in place: S' replaces the decisions once all of them are operands)
+        const auto mxs = mx.at(X, K);
         for (int j = 0; j < ic.ic_iter; ++j) {
             if (ic.do_phase_compensation > 0 && j == 0) {
                 const cf rot = phase_rotation(D, ic, red, M);
@@ -636,10 +687,10 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_receive(DevicePlan p
                     D[idx] = ic.active[dx.q] ? decide(D[idx], ic) : make_float2(0.f, 0.f);
             }
             __syncthreads();
-            cancel_rows(mx, V, D, S, p);
+            cancel_rows(mxs, V, D, S, p);
             __syncthreads();
             const bool last = (j == ic.ic_iter - 1);
-            row_dft<true>(mx, (last && !demap) ? o : D, V, K, M, M, 1, p.wM, invM);
+            row_dft<true>(mxs, (last && !demap) ? o : D, V, K, M, M, 1, p.wM, invM);
             __syncthreads();
             if (last && demap) emit_demapped(o, D, ic.io, K, M);
         }
@@ -864,13 +915,43 @@ bool generic_supports(int M, int K, bool one_tile)
 
 namespace {
 
-// LDS scratch of the matrix-core timeslot transforms (mx_dft), behind everything else a kernel keeps in LDS: 1024 KS bytes per group of 16 rows
-// (four planes of [4 KS][16] floats).  As many row groups as do not lower the number of workgroups a CU holds; rtc = 0: the vector-ALU
-// instantiation of the kernel -- no table in the plan, not even one group fits, or (unless the handle asks for the form wherever it fits) the form
-// would not pay: measured, it wins where the 16 x 16 x 4 operand tiles are well filled (M = 127: 64 output pairs x 64 sample pairs = 4 x 16 full
-// tiles; M = 33: 17 x 17 in 32 x 20), the block has a unit of work for each of its four wavefronts, and the scratch leaves the CU at least
-// two workgroups (the kernels are latency-bound: workgroups per CU decide) -- K=16 M=127 modulate 155 -> 130 us, MF demod 185 -> 137 us per
-// 4096 blocks; K=61 M=33 147 -> 180 us and K=37 M=127 (one workgroup per CU with the scratch) 350 -> 400 us, which therefore stay on the vector ALU.
+// Where the matrix-core form of the timeslot transforms (mx_dft) pays -- measured: where the 16 x 16 x 4 operand tiles are well filled (M = 127:
+// 64 output pairs x 64 sample pairs = 4 x 16 full tiles; M = 33: 17 x 17 in 32 x 20) and the block has a unit of work for each of its four wavefronts
+// (K=61 M=33: 147 -> 180 us per 4096 blocks, vector ALU kept).  A handle created in mode 2 (gfdm_hip_set_dft_matrix_cores) takes it wherever it fits.
+bool mx_pays(const DevicePlan& p)
+{
+    if (p.dft_always) return true;
+    const int RT = (p.K + 15) / 16, H = p.M / 2 + 1, KD = (p.M - 1) / 2 + 1 + ((p.M & 1) == 0 ? 1 : 0);
+    const double fill = (double)H * KD * p.K / ((double)(16 * p.dft_mt) * (4 * p.dft_ks) * (16 * RT));
+    return fill >= 0.7 && p.dft_mt * RT >= GT / 64;
+}
+size_t cu_workgroups(size_t lds_bytes) { return std::min<size_t>(8, LDS_MAX / lds_bytes); }
+
+// The operands of a 16-row group take 1024 KS bytes of LDS (four planes of [4 KS][16] floats).  The modulator and the receiver keep them in whichever
+// of their tiles is free at that point (MxDft::at): no LDS beyond the tiles, which are spaced so that one holds the operands of a whole block
+// (tile_stride >= N elements; K = 16, M = 127: 16 384 bytes of operands, 16 256 of samples).  These kernels are latency-bound -- a block alone on a CU
+// takes 18 us, four of them 24 us each (profiles/r03/stamps_generic_16_127.txt) -- so workgroups per CU decide: the form is not taken where the
+// wider spacing would cost the CU a workgroup and leave it fewer than two.  ntiles tiles + `other` bytes of LDS.
+struct MxAlias {
+    bool on;
+    int tile_stride;
+};
+MxAlias mx_alias(const DevicePlan& p, int ntiles, size_t other)
+{
+    MxAlias r{ false, p.N };
+    if (!p.dftA || !mx_pays(p)) return r;
+    const size_t xbytes = (size_t)((p.K + 15) / 16) * 1024 * (size_t)p.dft_ks;
+    const size_t ts = std::max<size_t>((size_t)p.N, xbytes / sizeof(cf));
+    const size_t lds = (size_t)ntiles * ts * sizeof(cf) + other, plain = (size_t)ntiles * (size_t)p.N * sizeof(cf) + other;
+    if (lds > LDS_MAX) return r;
+    if (!p.dft_always && cu_workgroups(lds) < 2 && cu_workgroups(lds) < cu_workgroups(plain)) return r;
+    r.on = true;
+    r.tile_stride = (int)ts;
+    return r;
+}
+
+// The stand-alone transform / cancellation kernels (one tile) and the global-scratch kernels keep a scratch region of their own behind everything
+// else in LDS, for as many row groups as do not lower the number of workgroups a CU holds; rtc = 0: the vector-ALU instantiation.
 struct MxLds {
     int off, rtc;
     size_t total;
@@ -878,19 +959,13 @@ struct MxLds {
 MxLds mx_lds(const DevicePlan& p, size_t used)
 {
     MxLds r{ 0, 0, used };
-    if (!p.dftA) return r;
+    if (!p.dftA || !mx_pays(p)) return r;
     const size_t per_rt = (size_t)1024 * (size_t)p.dft_ks, off = (used + 255) & ~(size_t)255;
     if (off + per_rt > LDS_MAX) return r;
     const int RT = (p.K + 15) / 16;
-    auto groups = [&](size_t bytes) { return std::min<size_t>(8, LDS_MAX / bytes); };
-    if (!p.dft_always) {
-        const int H = p.M / 2 + 1, KD = (p.M - 1) / 2 + 1 + ((p.M & 1) == 0 ? 1 : 0);
-        const double fill = (double)H * KD * p.K / ((double)(16 * p.dft_mt) * (4 * p.dft_ks) * (16 * RT));
-        if (fill < 0.7 || p.dft_mt * RT < GT / 64) return r;
-        if (groups(off + per_rt) < 2 && groups(off + per_rt) < groups(used)) return r;
-    }
+    if (!p.dft_always && cu_workgroups(off + per_rt) < 2 && cu_workgroups(off + per_rt) < cu_workgroups(used)) return r;
     int rtc = 1;
-    while (rtc < RT && groups(off + (size_t)(rtc + 1) * per_rt) == groups(off + per_rt)) ++rtc;
+    while (rtc < RT && cu_workgroups(off + (size_t)(rtc + 1) * per_rt) == cu_workgroups(off + per_rt)) ++rtc;
     r.off = (int)off;
     r.rtc = rtc;
     r.total = off + (size_t)rtc * per_rt;
@@ -919,13 +994,13 @@ struct Scratch {
 hipError_t launch_generic_modulate(const DevicePlan& p, const TxParams& tx, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    const size_t tab = generic_lds_bytes(p.N, 2), lds = tab + table_bytes(p);
-    if (lds <= LDS_MAX) {
-        const MxLds mx = mx_lds(p, lds);
-        auto kern = mx.rtc ? k_generic_modulate<false, true> : k_generic_modulate<false, false>;
-        hipError_t e = allow_lds(kern, mx.total);
+    if (generic_lds_bytes(p.N, 2) + table_bytes(p) <= LDS_MAX) {
+        const MxAlias al = mx_alias(p, 2, RED_BYTES + table_bytes(p));
+        const size_t tab = generic_lds_bytes(al.tile_stride, 2), lds = tab + table_bytes(p);
+        auto kern = al.on ? k_generic_modulate<false, true> : k_generic_modulate<false, false>;
+        hipError_t e = allow_lds(kern, lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, tx, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc }, out, in);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), lds, s, p, tx, (int)tab, TileArgs{ nullptr, 0, 0, 0, 0, al.on ? 1 : 0, al.tile_stride }, out, in);
         return hipGetLastError();
     }
     Scratch sc;
@@ -937,7 +1012,7 @@ hipError_t launch_generic_modulate(const DevicePlan& p, const TxParams& tx, cf* 
     if ((e = allow_lds(kern, mx.total)) != hipSuccess) return e;
     for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
         const int64_t n = std::min(sc.chunk, nblocks - b0);
-        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, tx, 0, TileArgs{ sc.base, tile_elems, b0, mx.off, mx.rtc }, out, in);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, tx, 0, TileArgs{ sc.base, tile_elems, b0, mx.off, mx.rtc, 0, p.N }, out, in);
         e = hipGetLastError();
     }
     const hipError_t e2 = sc.close();
@@ -966,13 +1041,14 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const
             if (generic_lds_bytes(p.N, 3) + extra + table_bytes(p) <= LDS_MAX) ntiles = 3; else s_in_global = 1;
         }
         if (!(s_in_global && ic.io.demap)) {                               // (a demapped output block is too small to park S in: GLOBAL below)
-            const size_t tab = (generic_lds_bytes(p.N, ntiles) + extra + 15) & ~(size_t)15, lds = tab + table_bytes(p);
-            const MxLds mx = mx_lds(p, lds);
-            auto kern = mx.rtc ? k_generic_receive<false, true> : k_generic_receive<false, false>;
-            hipError_t e = allow_lds(kern, mx.total);
+            // (the rounds of the matrix-core form keep S, the decisions and the operands in three LDS tiles)
+            const MxAlias al = s_in_global ? MxAlias{ false, p.N } : mx_alias(p, ntiles, RED_BYTES + extra + 16 + table_bytes(p));
+            const size_t tab = (generic_lds_bytes(al.tile_stride, ntiles) + extra + 15) & ~(size_t)15, lds = tab + table_bytes(p);
+            auto kern = al.on ? k_generic_receive<false, true> : k_generic_receive<false, false>;
+            hipError_t e = allow_lds(kern, lds);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, ic, est ? *est : kNoEst, eq_source, ntiles, mode,
-                               s_in_global, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc }, out, in, f_eq);
+            hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), lds, s, p, ic, est ? *est : kNoEst, eq_source, ntiles, mode,
+                               s_in_global, (int)tab, TileArgs{ nullptr, 0, 0, 0, 0, al.on ? 1 : 0, al.tile_stride }, out, in, f_eq);
             return hipGetLastError();
         }
     }
@@ -988,7 +1064,7 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const
     for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
         const int64_t n = std::min(sc.chunk, nblocks - b0);
         hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, ic, est ? *est : kNoEst, eq_source, ntiles,
-                           mode, 0, (int)tab, TileArgs{ sc.base, tile_elems, b0, mx.off, mx.rtc }, out, in, f_eq);
+                           mode, 0, (int)tab, TileArgs{ sc.base, tile_elems, b0, mx.off, mx.rtc, 0, p.N }, out, in, f_eq);
         e = hipGetLastError();
     }
     const hipError_t e2 = sc.close();
@@ -1004,7 +1080,7 @@ hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int6
         auto kern = mx.rtc ? k_generic_to_td<false, true> : k_generic_to_td<false, false>;
         hipError_t e = allow_lds(kern, mx.total);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc }, out, in);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc, 0, p.N }, out, in);
         return hipGetLastError();
     }
     Scratch sc;
@@ -1015,7 +1091,7 @@ hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int6
     if ((e = allow_lds(kern, mx.total)) != hipSuccess) return e;
     for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
         const int64_t n = std::min(sc.chunk, nblocks - b0);
-        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0, mx.off, mx.rtc }, out, in);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0, mx.off, mx.rtc, 0, p.N }, out, in);
         e = hipGetLastError();
     }
     const hipError_t e2 = sc.close();
@@ -1031,7 +1107,7 @@ hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, con
         auto kern = mx.rtc ? k_generic_cancel<false, true> : k_generic_cancel<false, false>;
         hipError_t e = allow_lds(kern, mx.total);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc }, out, td, fd);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(GT), mx.total, s, p, (int)tab, TileArgs{ nullptr, 0, 0, mx.off, mx.rtc, 0, p.N }, out, td, fd);
         return hipGetLastError();
     }
     Scratch sc;
@@ -1042,7 +1118,7 @@ hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, con
     if ((e = allow_lds(kern, mx.total)) != hipSuccess) return e;
     for (int64_t b0 = 0; b0 < nblocks && e == hipSuccess; b0 += sc.chunk) {
         const int64_t n = std::min(sc.chunk, nblocks - b0);
-        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0, mx.off, mx.rtc }, out, td, fd);
+        hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(GT), mx.total, s, p, 0, TileArgs{ sc.base, (int64_t)p.N, b0, mx.off, mx.rtc, 0, p.N }, out, td, fd);
         e = hipGetLastError();
     }
     const hipError_t e2 = sc.close();
@@ -1081,3 +1157,7 @@ hipError_t launch_prepare_for_zf(cf* out, const cf* in, int64_t n, hipStream_t s
 }
 
 }  // namespace gfdm
+
+#ifdef GFDM_STAMPS
+extern "C" int gfdm_debug_set_stamp_buffer_generic(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(gfdm::g_gstamp_buf), &p, sizeof(p)); }
+#endif
