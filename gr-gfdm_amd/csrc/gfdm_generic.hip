@@ -108,6 +108,21 @@ __device__ __forceinline__ void stream_in(cf* dst, const cf* __restrict__ src, i
     stream_in(dst, src, n, [](cf v, int) { return v; });
 }
 
+// Threads own COLUMNS of a [rows][M] tile: thread t takes column t % M of the rows t / M, t / M + G, ... (G = GT / M row groups; M > GT: columns
+// t, t + GT, ... of every row), so that whatever depends on the column only -- the filter taps, which live in global memory: an L2 round trip of
+// ~0.5 us each -- is fetched once per thread instead of once per element.  body(m, first row, row step).
+template <class Body>
+__device__ __forceinline__ void for_columns(int M, Body body)
+{
+    if (M <= GT) {
+        const int G = GT / M, g = threadIdx.x / M, m = threadIdx.x - g * M;
+        if (g < G) body(m, g, G);
+    } else {
+        for (int m = threadIdx.x; m < M; m += GT) body(m, 0, 1);
+    }
+}
+constexpr int TAPS_IN_REGS = 4;    // overlap factors up to this keep a column's taps in registers (the reference's flowgraphs use 2; longer filters take the loop)
+
 // One pass over the samples v_p and the roots w_p = W_M^{p m} yields TWO outputs of the direct DFT, m and M - m (W_M^{p (M - m)} = conj(w_p)),
 // and it takes the samples in PAIRS as well: w_{M - p} = conj(w_p), so with a = v_p + v_{M-p}, b = v_p - v_{M-p} and w_p = (c, s)
 //     v_p w_p + v_{M-p} conj(w_p) = a c + j b s          v_p conj(w_p) + v_{M-p} w_p = a c - j b s
@@ -531,17 +546,41 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_modulate(DevicePlan 
     GFDM_GSTAMP(2);
     // gather form of the filter + overlap-add scatter (:116-132):
     //   Y[j][m] = sum_i D[(j - i + L/2) mod K][m] * taps[((i + L/2) % L) M + m],  m < part_len
-    DivStep jx(threadIdx.x, GT, M);
-    for (int idx = threadIdx.x; idx < N; idx += GT, jx.next()) {
-        const int j = jx.q, m = jx.r;
-        cf acc = make_float2(0.f, 0.f);
-        if (m < p.part_len) {
-            for (int i = 0; i < L; ++i) {
-                const int k = ((j - i + L / 2) % K + K) % K;
-                acc = cfma(D[k * M + m], p.taps[((i + L / 2) % L) * M + m], acc);
+    if (L <= TAPS_IN_REGS) {
+        for_columns(M, [&](int m, int j0, int js) {
+            cf tp[TAPS_IN_REGS];
+#pragma unroll
+            for (int i = 0; i < TAPS_IN_REGS; ++i) tp[i] = (i < L && m < p.part_len) ? p.taps[((i + L / 2) % L) * M + m] : make_float2(0.f, 0.f);
+            int k0 = (j0 + L / 2) % K;
+            const int ks = js % K;
+            for (int j = j0; j < K; j += js) {
+                cf acc = make_float2(0.f, 0.f);
+                int k = k0;
+#pragma unroll
+                for (int i = 0; i < TAPS_IN_REGS; ++i) {
+                    if (i < L) {
+                        acc = cfma(D[k * M + m], tp[i], acc);
+                        if (--k < 0) k = K - 1;
+                    }
+                }
+                Y[j * M + m] = acc;
+                k0 += ks;
+                if (k0 >= K) k0 -= K;
             }
+        });
+    } else {
+        DivStep jx(threadIdx.x, GT, M);
+        for (int idx = threadIdx.x; idx < N; idx += GT, jx.next()) {
+            const int j = jx.q, m = jx.r;
+            cf acc = make_float2(0.f, 0.f);
+            if (m < p.part_len) {
+                for (int i = 0; i < L; ++i) {
+                    const int k = ((j - i + L / 2) % K + K) % K;
+                    acc = cfma(D[k * M + m], p.taps[((i + L / 2) % L) * M + m], acc);
+                }
+            }
+            Y[idx] = acc;
         }
-        Y[idx] = acc;
     }
     __syncthreads();
     GFDM_GSTAMP(3);
@@ -549,9 +588,18 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_modulate(DevicePlan 
     GFDM_GSTAMP(4);
     cf* u = (z == Y) ? D : Y;
     DivStep qx(threadIdx.x, GT, M);
-#pragma unroll 4
-    for (int idx = threadIdx.x; idx < N; idx += GT, qx.next()) {   // twiddle conj(W_N^{q m})
-        u[idx] = cmulj(z[idx], p.wN[qx.q * qx.r]);
+    for (int idx0 = threadIdx.x; idx0 < N; idx0 += 8 * GT) {       // twiddle conj(W_N^{q m}): eight roots (global memory) in flight per thread
+        cf w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (idx0 + j * GT < N) w[j] = p.wN[qx.q * qx.r];
+            qx.next();
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = idx0 + j * GT;
+            if (idx < N) u[idx] = cmulj(z[idx], w[j]);
+        }
     }
     __syncthreads();
     GFDM_GSTAMP(5);
@@ -611,8 +659,10 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_receive(DevicePlan p
         __syncthreads();
     }
 
+    GFDM_GSTAMP(0);
     stream_in(t1, x, N);
     __syncthreads();
+    GFDM_GSTAMP(1);
     // A[q][m] = W_N^{q m} * sum_p x[K p + q] W_M^{p m}
     // (matrix-core form without a scratch of its own: the operands go to the free tile t0, the result replaces the samples in t1)
     cf* A0 = mx.in_place() ? t1 : t0;
@@ -624,8 +674,10 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_receive(DevicePlan p
                           if (m2 != m) A0[q * M + m2] = cmul(acc.with_conj(), p.wN[q * m2]);
                       });
     __syncthreads();
+    GFDM_GSTAMP(2);
     cf* X = col_fft<false>(A0, A1, p);                             // X[j][m] = FFT_N(x)[M j + m]       :304-305
     cf* U = (X == A0) ? A1 : A0;
+    GFDM_GSTAMP(3);
     if (eq) {                                                      // one-tap equaliser                 :315-316
         stream_in(X, eq, N, [&](cf e, int idx) { return cdiv(X[idx], e); });
         __syncthreads();
@@ -635,25 +687,51 @@ __global__ __launch_bounds__(GT, MX ? 4 : 8) void k_generic_receive(DevicePlan p
     }
     // S[k][m] = sum_i taps[((i + L/2) % L) M + m] * X[((k + i + K - L/2) % K) M + m]                    :165-192
     cf* Sdst = (mode == RX_FD) ? o : U;
-    DivStep fx(threadIdx.x, GT, M);
-    for (int idx = threadIdx.x; idx < N; idx += GT, fx.next()) {
-        const int k = fx.q, m = fx.r;
-        cf acc = make_float2(0.f, 0.f);
-        int row = k - L / 2, part = L / 2;                         // row (k + i - L/2) mod K, tap part (i + L/2) mod L
-        if (row < 0) row += K;
-        for (int i = 0; i < L; ++i) {
-            acc = cfma(p.taps[part * M + m], X[row * M + m], acc);
-            if (++row == K) row = 0;
-            if (++part == L) part = 0;
+    if (L <= TAPS_IN_REGS) {
+        for_columns(M, [&](int m, int k0, int ks) {
+            cf tp[TAPS_IN_REGS];
+#pragma unroll
+            for (int i = 0; i < TAPS_IN_REGS; ++i) tp[i] = (i < L) ? p.taps[((i + L / 2) % L) * M + m] : make_float2(0.f, 0.f);
+            int r0 = ((k0 - L / 2) % K + K) % K;                    // row (k + i - L/2) mod K, tap part (i + L/2) mod L
+            const int rs = ks % K;
+            for (int k = k0; k < K; k += ks) {
+                cf acc = make_float2(0.f, 0.f);
+                int row = r0;
+#pragma unroll
+                for (int i = 0; i < TAPS_IN_REGS; ++i) {
+                    if (i < L) {
+                        acc = cfma(tp[i], X[row * M + m], acc);
+                        if (++row == K) row = 0;
+                    }
+                }
+                Sdst[k * M + m] = acc;
+                r0 += rs;
+                if (r0 >= K) r0 -= K;
+            }
+        });
+    } else {
+        DivStep fx(threadIdx.x, GT, M);
+        for (int idx = threadIdx.x; idx < N; idx += GT, fx.next()) {
+            const int k = fx.q, m = fx.r;
+            cf acc = make_float2(0.f, 0.f);
+            int row = k - L / 2, part = L / 2;
+            if (row < 0) row += K;
+            for (int i = 0; i < L; ++i) {
+                acc = cfma(p.taps[part * M + m], X[row * M + m], acc);
+                if (++row == K) row = 0;
+                if (++part == L) part = 0;
+            }
+            Sdst[idx] = acc;
         }
-        Sdst[idx] = acc;
     }
     if (mode == RX_FD) return;
     __syncthreads();
+    GFDM_GSTAMP(4);
     const float invM = 1.f / (float)M;
     if (mode == RX_DEMOD || ic.ic_iter <= 0) {
         if (!demap) {
             row_dft<true>(mx.at(X, K), o, U, K, M, M, 1, p.wM, invM);      // d = IFFT_M(S_k) / M                :211-225
+            GFDM_GSTAMP(5);
         } else {
             cf* d = mx.in_place() ? U : X;                              // (X holds the operands then)
             row_dft<true>(mx.at(X, K), d, U, K, M, M, 1, p.wM, invM);
@@ -941,7 +1019,7 @@ MxAlias mx_alias(const DevicePlan& p, int ntiles, size_t other)
     MxAlias r{ false, p.N };
     if (!p.dftA || !mx_pays(p)) return r;
     const size_t xbytes = (size_t)((p.K + 15) / 16) * 1024 * (size_t)p.dft_ks;
-    const size_t ts = std::max<size_t>((size_t)p.N, xbytes / sizeof(cf));
+    const size_t ts = (std::max<size_t>((size_t)p.N, xbytes / sizeof(cf)) + 1) & ~(size_t)1;        // (even: the operand reads are 16 bytes wide)
     const size_t lds = (size_t)ntiles * ts * sizeof(cf) + other, plain = (size_t)ntiles * (size_t)p.N * sizeof(cf) + other;
     if (lds > LDS_MAX) return r;
     if (!p.dft_always && cu_workgroups(lds) < 2 && cu_workgroups(lds) < cu_workgroups(plain)) return r;
