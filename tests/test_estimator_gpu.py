@@ -212,10 +212,11 @@ def test_estimator_pybind_surface():
 
 
 @pytest.mark.parametrize("M,K,L,A,dc_free", [(9, 64, 2, 52, True), (5, 64, 2, 52, True), (15, 128, 2, 110, False), (5, 32, 2, 24, True), (9, 32, 2, 28, False), (15, 128, 4, 110, True),
-                                             (31, 256, 2, 220, True), (7, 12, 2, 8, True), (3, 48, 2, 40, False)])
+                                             (31, 256, 2, 220, True), (7, 12, 2, 8, True), (3, 48, 2, 40, False), (127, 16, 2, 12, True)])
 def test_receivers_with_fused_estimator(M, K, L, A, dc_free):
     """demodulate_estimated == estimate_frame followed by demodulate_equalize (the oracle's chain), for the plain receiver and the
-    IC receiver, on plain blocks and on bursts (preamble + frame in one buffer, demapped output); row-lane and generic shapes."""
+    IC receiver, on plain blocks and on bursts (preamble + frame in one buffer, demapped output); row-lane and generic shapes (M = 127: the generic
+    family with its transforms and cancellation rounds on the matrix cores, operands in the free LDS tile)."""
     import gfdm_amd
     rng = np.random.default_rng(M * K + A)
     N, B = M * K, 7

@@ -527,7 +527,7 @@ def test_phase_compensation_removes_a_common_phase():
     the input, without it the phase stays in the output; both also against the oracle."""
     import gfdm_amd
     from test_oracle import phase_case
-    for (M, K, L, alpha) in ((9, 64, 2, 0.2), (15, 128, 4, 0.2), (5, 32, 2, 0.5)):
+    for (M, K, L, alpha) in ((9, 64, 2, 0.2), (15, 128, 4, 0.2), (5, 32, 2, 0.5), (127, 16, 2, 0.3)):     # (M = 127: generic family, rounds on the matrix cores)
         nt, smap, x, keep = phase_case(M, K, L, alpha)
         B = x.shape[0]
         taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
