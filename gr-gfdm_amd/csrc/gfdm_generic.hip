@@ -191,24 +191,9 @@ __device__ __forceinline__ void paired_dft_blocked(int rows, int M, const cf* __
 //   D: lane l holds the outputs m = 16 mt + 4 (l >> 4) + i, i < 4, of row l & 15: Q1..Q4 of one (row, output pair) end up in ONE lane, so the epilogue is
 //      the same fin(r, m, DftPair) as in the vector-ALU form.
 // A wavefront takes (output tile, row group) units; the scratch holds rtc row groups at a time (launch code: as many as keep the blocks per CU).
-struct MxDft {
-    const float* A;
-    float* xs;
-    int rtc, MT, KS;
-    int alias;             // 1: no scratch of its own -- a transform borrows the tile that is free at that point (`at`) and takes all row groups at once
-    // the transform of `rows` rows whose operands go to the free tile `tile` (alias form; else the scratch region as it is)
-    __device__ __forceinline__ MxDft at(cf* tile, int rows) const
-    {
-        MxDft m = *this;
-        if (alias) { m.xs = reinterpret_cast<float*>(tile); m.rtc = (rows + 15) / 16; }
-        return m;
-    }
-    __device__ __forceinline__ bool in_place() const { return alias != 0; }
-};
-
-typedef float mx_f4 __attribute__((ext_vector_type(4)));
-
-// A operands of one output tile, k-steps [ks0, ks0 + 16): 32 registers, loaded ahead of the code that waits for the samples (the table does not depend on them)
+// A operands of one output tile, k-steps [ks0, ks0 + 16): 32 registers.  The table does not depend on the samples: a kernel fetches the operands of the
+// output tile its wavefront starts with at ENTRY (MxDft::preload) and keeps them -- every transform of the kernel uses the same table, and with up
+// to 16 k-steps and one unit per wavefront (M = 127, K = 16) no transform waits for the L2 again.
 struct MxA {
     float c[16], s[16];
     __device__ __forceinline__ void load(const float* __restrict__ A, int ks0, int KS)
@@ -222,18 +207,38 @@ struct MxA {
     }
 };
 
+struct MxDft {
+    const float* A;
+    float* xs;
+    int rtc, MT, KS;
+    int alias;             // 1: no scratch of its own -- a transform borrows the tile that is free at that point (`at`) and takes all row groups at once
+    // the transform of `rows` rows whose operands go to the free tile `tile` (alias form; else the scratch region as it is)
+    __device__ __forceinline__ MxDft at(cf* tile, int rows) const
+    {
+        MxDft m = *this;
+        if (alias) { m.xs = reinterpret_cast<float*>(tile); m.rtc = (rows + 15) / 16; }
+        return m;
+    }
+    __device__ __forceinline__ bool in_place() const { return alias != 0; }
+    MxA a;                 // operands of output tile a_mt, first 16 k-steps
+    int a_mt;
+    __device__ __forceinline__ void preload()
+    {
+        a_mt = (int)(threadIdx.x >> 6) % MT;
+        a.load(A + (size_t)a_mt * KS * 128 + (threadIdx.x & 63), 0, KS);
+    }
+};
+
+typedef float mx_f4 __attribute__((ext_vector_type(4)));
+
 template <class Src, class Fin>
 __device__ __forceinline__ void mx_dft(const MxDft& mx, int rows, int M, Src src, Fin fin)
 {
     const int H = M / 2 + 1, HP = (M - 1) / 2, KD = HP + 1 + ((M & 1) == 0 ? 1 : 0), KDp = 4 * mx.KS, RT = (rows + 15) / 16;
     const int plane = KDp * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    MxA a;
-    int a_mt = -1;                                                 // the output tile whose first 16 k-steps sit in a
-    if (wave < mx.MT * ((RT < mx.rtc) ? RT : mx.rtc)) {
-        a_mt = wave % mx.MT;
-        a.load(mx.A + (size_t)a_mt * mx.KS * 128 + lane, 0, mx.KS);
-    }
+    MxA a = mx.a;                                                  // (fetched at kernel entry)
+    int a_mt = mx.a_mt;                                            // the output tile whose first 16 k-steps sit in a
     for (int rt0 = 0; rt0 < RT; rt0 += mx.rtc) {
         const int nrt = (RT - rt0 < mx.rtc) ? RT - rt0 : mx.rtc;
         if (rt0) __syncthreads();                                  // the previous chunk's operands are spent
@@ -512,7 +517,11 @@ struct TileArgs {
 template <bool MX>
 __device__ __forceinline__ auto mx_of(const DevicePlan& p, const TileArgs& ta, unsigned char* smem)
 {
-    if constexpr (MX) return MxDft{ p.dftA, reinterpret_cast<float*>(smem + ta.xs_off), ta.xs_rtc, p.dft_mt, p.dft_ks, ta.xs_alias };
+    if constexpr (MX) {
+        MxDft m{ p.dftA, reinterpret_cast<float*>(smem + ta.xs_off), ta.xs_rtc, p.dft_mt, p.dft_ks, ta.xs_alias, {}, -1 };
+        m.preload();
+        return m;
+    }
     else return NoMx{};
 }
 
