@@ -1,6 +1,8 @@
 """Random (timeslots, subcarriers, overlap) shapes, random subcarrier maps, complex taps, every receive mode, frames + demapper,
 the fused transmitter and the stand-alone stages, against the float64 oracle.  Not part of the test suite (run-time instantiation of
-many shapes takes minutes):   python3 scratch/fuzz_shapes.py [seed] [seconds]"""
+many shapes takes minutes):   python3 scratch/fuzz_shapes.py [seed] [seconds]
+FUZZ_GENERIC=1: every handle on the generic kernel family (up to 300 timeslots, blocks up to 30 000 samples incl. the global-scratch form), the
+matrix-core mode of its timeslot transforms (gfdm_hip_set_dft_matrix_cores 0 / 1 / 2) drawn per shape."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "gr-gfdm_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -12,6 +14,8 @@ from gfdm_amd.filters import get_frequency_domain_filter
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 600.0
 rng = np.random.default_rng(seed)
+GENERIC = bool(os.environ.get("FUZZ_GENERIC"))
+import contextlib
 TOL, GUARD = 1e-5, 1e-4
 
 
@@ -32,7 +36,14 @@ while time.time() - t0 < budget:
     else: K = int(rng.integers(2, 300))
     M = int(rng.integers(1, 34)) if rng.random() < 0.85 else int(rng.integers(34, 70))
     L = int(rng.choice([2, 2, 2, 3, 4, 5, 6, 8]))
-    if L > K or M * K > 12000: continue
+    mxmode = 1
+    if GENERIC:
+        K = int(rng.integers(2, 70)) if rng.random() < 0.8 else int(rng.integers(70, 400))
+        M = int(rng.integers(20, 140)) if rng.random() < 0.8 else int(rng.integers(140, 300))
+        mxmode = int(rng.integers(0, 3))
+        gfdm_amd.set_dft_matrix_cores(mxmode)
+        if L > K or M * K > 30000: continue
+    elif L > K or M * K > 12000: continue
     N, B = M * K, int(rng.integers(1, 9))
     alpha = float(rng.choice([0.1, 0.2, 0.35, 0.5, 1.0]))
     taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
@@ -42,10 +53,11 @@ while time.time() - t0 < budget:
     A = int(rng.integers(1, K + 1))
     smap = np.sort(rng.choice(K, A, replace=False))
     ic_iter = int(rng.integers(0, 4)); pc = int(rng.random() < 0.2)
-    tag = "M=%d K=%d L=%d A=%d B=%d ic=%d pc=%d a=%.2f" % (M, K, L, A, B, ic_iter, pc, alpha)
+    tag = "M=%d K=%d L=%d A=%d B=%d ic=%d pc=%d a=%.2f mx=%d" % (M, K, L, A, B, ic_iter, pc, alpha, mxmode)
     try:
-        mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
-        adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, ic_iter, R.qpsk_points(), do_phase_compensation=pc)
+        with (gfdm_amd.generic_family_for_testing() if GENERIC else contextlib.nullcontext()):
+            mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+            adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, smap, ic_iter, R.qpsk_points(), do_phase_compensation=pc)
         fams[dem.kernel_name()] = fams.get(dem.kernel_name(), 0) + 1
         d = np.zeros((B, K, M), complex); d[:, smap, :] = qpsk((B, A, M)); d = d.reshape(B, N)
         x = R.modulate(d, nt, M, K, L)
@@ -75,7 +87,8 @@ while time.time() - t0 < budget:
         pre = rng.standard_normal(5) + 1j * rng.standard_normal(5)
         nin = int(rng.integers(1, A * M + 1))
         sym = qpsk((B, nin))
-        tx = gfdm_amd.Transmitter(M, K, A, cp, cs, ramp, smap, per_ts, L, taps, window, [shift], [pre])
+        with (gfdm_amd.generic_family_for_testing() if GENERIC else contextlib.nullcontext()):
+            tx = gfdm_amd.Transmitter(M, K, A, cp, cs, ramp, smap, per_ts, L, taps, window, [shift], [pre])
         errs.append(rel(tx.transmit(sym, ninput_size=nin)[0], R.transmit(sym, nt, M, K, L, smap, per_ts, cp, cs, ramp, window, shift, pre)))
         rm = gfdm_amd.ResourceMapper(M, K, A, smap, per_ts)
         grid = rm.map_to_resources(sym, ninput_size=nin)
