@@ -190,7 +190,9 @@ __device__ __forceinline__ void paired_dft_blocked(int rows, int M, const cf* __
 //              [4 KS][16 rows] floats: the operand of k-step ks is the 64 consecutive floats at 64 ks (lane l: k = l >> 4, row l & 15, conflict-free)
 //   D: lane l holds the outputs m = 16 mt + 4 (l >> 4) + i, i < 4, of row l & 15: Q1..Q4 of one (row, output pair) end up in ONE lane, so the epilogue is
 //      the same fin(r, m, DftPair) as in the vector-ALU form.
-// A wavefront takes (output tile, row group) units; the scratch holds rtc row groups at a time (launch code: as many as keep the blocks per CU).
+// A wavefront takes (output tile, row group) units.  The operands sit in whichever LDS tile is free at that point (modulator / receiver kernels: MxDft::at,
+// all row groups at once) or in a scratch region of rtc row groups (stand-alone and global-scratch kernels); launch code: mx_alias / mx_lds.
+
 // A operands of one output tile, k-steps [ks0, ks0 + 16): 32 registers.  The table does not depend on the samples: a kernel fetches the operands of the
 // output tile its wavefront starts with at ENTRY (MxDft::preload) and keeps them -- every transform of the kernel uses the same table, and with up
 // to 16 k-steps and one unit per wavefront (M = 127, K = 16) no transform waits for the L2 again.
