@@ -205,7 +205,7 @@ def test_row_lane_kernels_build_through_hiprtc(tmp_path, monkeypatch):
 
 
 def test_precompile_and_library_switches_without_a_gpu(tmp_path, monkeypatch):
-    """gfdm_hip_precompile (the deployment step of INTEGRATION.md) fills the code-object cache without a handle or a GPU; the two
+    """gfdm_hip_precompile (the deployment step of INTEGRATION.md) fills the code-object cache without a handle or a GPU; the three
     library switches keep their mode and clamp it; python -m gfdm_amd.precompile is the command-line form."""
     import subprocess
     import sys
@@ -228,6 +228,11 @@ def test_precompile_and_library_switches_without_a_gpu(tmp_path, monkeypatch):
         assert gfdm_amd.set_ic_matrix_cores(7) == 2 and gfdm_amd.set_ic_matrix_cores(0) == 2 and gfdm_amd.set_ic_matrix_cores(mx) == 0
     finally:
         gfdm_amd.set_ic_matrix_cores(mx)
+    dx = gfdm_amd.set_dft_matrix_cores(2)                              # (default 1: the generic family's transforms on the matrix cores where faster)
+    try:
+        assert dx == 1 and gfdm_amd.set_dft_matrix_cores(9) == 2 and gfdm_amd.set_dft_matrix_cores(False) == 2 and gfdm_amd.set_dft_matrix_cores(dx) == 0
+    finally:
+        gfdm_amd.set_dft_matrix_cores(dx)
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "gr-gfdm_amd", "python"), GFDM_HIP_CACHE_DIR=str(tmp_path))
     r = subprocess.run([sys.executable, "-m", "gfdm_amd.precompile", "6", "16", "2", "--parts", "rx", "9", "64", "2", "127", "16", "2"],
                        env=env, capture_output=True, text=True)
