@@ -625,6 +625,11 @@ int gfdm_hip_precompile(int timeslots, int subcarriers, int overlap, unsigned pa
     return GFDM_HIP_OK;
 }
 
+void gfdm_hip_quiesce(void)
+{
+    gfdm::jit_quiesce();
+}
+
 int gfdm_hip_set_ic_matrix_cores(int mode)
 {
     return g_ic_mfma.exchange(mode < 0 ? 0 : mode > 2 ? 2 : mode);

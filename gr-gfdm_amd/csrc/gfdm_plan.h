@@ -121,6 +121,8 @@ hipError_t jit_launch_estimate(JitCache* cache, const EstPlan& e, cf* out, const
 bool jit_cached(int M, int K, int L, int part);               // the part's code object is in the disk cache
 // compile / load on a background thread; *state: 0 running, 1 ready, -1 failed
 void jit_prepare_async(int M, int K, int L, unsigned parts, int device, std::shared_ptr<std::atomic<int>> state);
+// drop the queued background builds, let the ones in flight finish WITHOUT touching the GPU, wait for them (exit path; gfdm_hip_quiesce)
+void jit_quiesce();
 // error reporting shared by the translation units of the C-ABI (thread-local message behind gfdm_hip_last_error)
 int api_fail(int code, const std::string& msg);
 int api_fail_hip(hipError_t e, const char* what);

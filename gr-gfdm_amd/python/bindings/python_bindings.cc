@@ -14,6 +14,7 @@
 #include <gfdm/resource_mapper_kernel_cc.h>
 #include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm/transmitter_kernel.h>
+#include <gfdm_hip.h>
 
 
 namespace py = pybind11;
@@ -121,6 +122,8 @@ py::array_t<cfloat> run_estimated(Kernel& self, const carray& x, const carray& p
 PYBIND11_MODULE(gfdm_python, m)
 {
     m.doc() = "GFDM modulator / receiver kernels on AMD MI355X (HIP) behind gr-gfdm's kernel-class API";
+    // background builds of run-time instantiated kernels must not outlive the interpreter's tear-down (gfdm_hip_quiesce, include/gfdm_hip.h)
+    py::module_::import("atexit").attr("register")(py::cpp_function([]() { gfdm_hip_quiesce(); }));
 
     py::class_<modulator_kernel_cc>(m, "Modulator")
         .def(py::init<int, int, int, std::vector<cfloat>>(), py::arg("timeslots"), py::arg("subcarriers"), py::arg("overlap"),

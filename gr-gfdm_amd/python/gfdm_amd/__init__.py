@@ -5,4 +5,4 @@
 """
 from . import filters  # noqa: F401
 from .capi import (AdvancedReceiver, ChannelEstimator, CyclicPrefixer, Demodulator, GfdmHipError, Modulator, ResourceMapper, Transmitter, exported_symbols,  # noqa: F401
-                   JIT_AUTO, JIT_BACKGROUND, JIT_IN_CONSTRUCTOR, JIT_OFF, generic_family_for_testing, lib, precompile, set_dft_matrix_cores, set_ic_matrix_cores, set_jit)
+                   JIT_AUTO, JIT_BACKGROUND, JIT_IN_CONSTRUCTOR, JIT_OFF, generic_family_for_testing, lib, precompile, quiesce, set_dft_matrix_cores, set_ic_matrix_cores, set_jit)

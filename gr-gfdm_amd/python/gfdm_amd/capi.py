@@ -52,6 +52,7 @@ def lib():
         "gfdm_hip_set_jit": (i32, [i32]),
         "gfdm_hip_precompile": (i32, [i32, i32, i32, ctypes.c_uint]),
         "gfdm_hip_set_ic_matrix_cores": (i32, [i32]),
+        "gfdm_hip_quiesce": (None, []),
         "gfdm_hip_set_dft_matrix_cores": (i32, [i32]),
         "gfdm_hip_jit_build_for_testing": (i32, [i32, i32, i32, i32]),
         "gfdm_hip_version": (cp, []),
@@ -162,6 +163,9 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     L._gfdm_symbols = sorted(sig)
+    # background builds must not outlive the interpreter's tear-down of the HIP runtime (gfdm_hip_quiesce: include/gfdm_hip.h)
+    import atexit
+    atexit.register(L.gfdm_hip_quiesce)
     _lib = L
     return L
 
@@ -246,6 +250,12 @@ def set_ic_matrix_cores(mode):
     only, 1 / True (default) matrix cores where they are the faster form (subcarriers >= 128), 2 matrix cores wherever the form applies.
     Returns the previous mode."""
     return lib().gfdm_hip_set_ic_matrix_cores(int(mode))
+
+
+def quiesce():
+    """gfdm_hip_quiesce: drop the queued background builds of the run-time instantiated kernels, wait for the ones in flight (they finish
+    their compile without touching the GPU).  Registered with atexit when the library is loaded."""
+    lib().gfdm_hip_quiesce()
 
 
 def set_dft_matrix_cores(mode):

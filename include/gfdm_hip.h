@@ -86,6 +86,12 @@ int gfdm_hip_set_jit(int mode);
  * 4 estimator (0 = all).  Returns GFDM_HIP_OK also for shapes that are compiled into the library; GFDM_HIP_EUNSUPPORTED for shapes only
  * the generic family serves.  Command line: python -m gfdm_amd.precompile <timeslots> <subcarriers> <overlap> [...]. */
 int gfdm_hip_precompile(int timeslots, int subcarriers, int overlap, unsigned parts);
+/* Stops the background builds of gfdm_hip_set_jit modes 2 / 3: what is still queued is dropped (those handles stay on the generic kernels), the
+ * builds in flight finish their compile (the code object still reaches the disk cache) without touching the GPU, and the call returns when the
+ * two pool threads are idle -- at most one compile (10-70 s) later.  The library does this by itself when it is unloaded; an application that
+ * tears the HIP runtime down before that (an interpreter at exit: the Python package registers it with atexit) calls it first.  Later requests
+ * start the pool again. */
+void gfdm_hip_quiesce(void);
 /* The interference-cancellation rounds of the advanced receiver (lib/advanced_receiver_kernel_cc.cc:56-76, lib/receiver_kernel_cc.cc:274-299)
  * can run on the matrix cores (v_mfma_f32_16x16x32_f16; the QPSK decisions are exact in f16, the IC taps enter as a three-term f16 split with
  * 33 significant bits, sums in f32) where that form applies: QPSK sign decisions, a real even IC kernel (any real, even prototype filter),

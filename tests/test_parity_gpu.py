@@ -947,6 +947,45 @@ def test_blocks_larger_than_the_lds(M, K, L):
     assert rel_err(first.cpu().numpy()[keep], ref[keep]) < TOL
 
 
+def test_process_exit_with_background_builds_in_flight(tmp_path):
+    """A process that ends while the kernels of new shapes are still being instantiated in the background (gfdm_hip_set_jit modes 2 / 3: a flowgraph
+    torn down right after it was built) must exit cleanly and soon: the builds run on a pool of two threads fed from a queue, gfdm_hip_quiesce --
+    registered with atexit by both Python surfaces, and the library's own unload path -- drops what is queued and lets the builds in flight finish
+    without touching the GPU.  (Before the pool existed every shape started a thread of its own and an interpreter exit with dozens of compiles in
+    flight ended in a segmentation fault.)  Eight uncached shapes, every handle answers from the generic family meanwhile."""
+    import subprocess
+    import sys
+    import time
+    code = r"""
+import os, sys, time
+sys.path.insert(0, os.path.join(%r, "gr-gfdm_amd", "python")); sys.path.insert(0, os.path.join(%r, "gr-gfdm_amd", "lib")); sys.path.insert(0, os.path.join(%r, "oracle"))
+import numpy as np
+import gfdm_amd, gfdm_python
+import gfdm_ref as R
+from gfdm_amd.filters import get_frequency_domain_filter
+gfdm_amd.set_jit(gfdm_amd.JIT_BACKGROUND)
+rng = np.random.default_rng(5)
+keep = []
+for i, (M, K) in enumerate(((17, 16), (18, 32), (19, 16), (20, 8), (21, 32), (22, 16), (23, 8), (25, 16))):
+    taps = get_frequency_domain_filter("rrc", 0.3, M, K, 2)
+    t0 = time.time()
+    dem = gfdm_amd.Demodulator(M, K, 2, taps) if i %% 2 else gfdm_python.Demodulator(M, K, 2, list(taps.astype(np.complex64)))
+    assert time.time() - t0 < 2.0, "constructor waited for a compile"
+    x = (rng.standard_normal(M * K) + 1j * rng.standard_normal(M * K)).astype(np.complex64)
+    y = np.asarray(dem.demodulate(x)).ravel()
+    ref = R.demodulate(x[None, :], R.normalize_taps(taps, M), M, K, 2)[0]
+    assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 1e-5
+    keep.append(dem)
+print("built", len(keep), flush=True)
+""" % ((os.path.dirname(os.path.dirname(os.path.abspath(__file__))),) * 3)
+    env = dict(os.environ, GFDM_HIP_CACHE_DIR=str(tmp_path))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "built 8" in r.stdout
+    assert time.time() - t0 < 300                                  # two builds in flight at most (10-70 s each), the other six dropped
+
+
 def test_damaged_cache_entry_is_recompiled(tmp_path, monkeypatch):
     """a truncated code object in the disk cache of the run-time instantiated kernels must not strand the shape on the generic family:
     the part is compiled afresh and the cache entry replaced"""
