@@ -5,6 +5,7 @@
 #include "gfdm_plan.h"
 #include "gfdm_rowgeom.h"
 #include "gfdm_tx.h"
+#include "gfdm_hostpipe.h"
 
 #include <cmath>
 #include <complex>
@@ -67,16 +68,7 @@ struct Plan {
     std::vector<cf> h_taps, h_ictaps;
     cf* d_tables = nullptr;          // one allocation: taps | ictaps | wM | wK | wN
     hipStream_t stream = nullptr;    // private stream for the *_host entry points
-    cf* stage[3] = { nullptr, nullptr, nullptr };
-    size_t stage_elems[3] = { 0, 0, 0 };
-    // small *_host calls (a GNU Radio wrapper handing over one block at a time): one pinned, GPU-mapped host buffer -- the kernel
-    // reads its input and writes its output straight across PCIe, which saves the two copy commands of the staged path
-    cf* pinned = nullptr;            // host address
-    cf* pinned_dev = nullptr;        // the same memory as the GPU sees it
-    size_t pinned_elems = 0;
-    unsigned* ticket = nullptr;      // completion ticket of the small host calls (pinned, GPU-mapped; wait_ticket)
-    unsigned* ticket_dev = nullptr;
-    unsigned ticket_next = 0;
+    gfdm::HostPipe pipe;             // the host-buffer batch path: pinned staging sets, completion ticket (gfdm_hostpipe.h)
     std::string kernel_name;
     const cf* d_twT = nullptr;       // [M][K] twiddles W_N^{q m}, transposed so that lane q reads them coalesced (row-lane family)
     int family = gfdm::FAMILY_GENERIC;
@@ -101,9 +93,7 @@ struct Plan {
         int prev = 0;
         bool restore = (hipGetDevice(&prev) == hipSuccess);
         (void)hipSetDevice(device);
-        for (auto& s : stage) if (s) (void)hipFree(s);
-        if (pinned) (void)hipHostFree(pinned);
-        if (ticket) (void)hipHostFree(ticket);
+        pipe.release();
         if (d_tables) (void)hipFree(d_tables);
         if (stream) (void)hipStreamDestroy(stream);
         if (restore) (void)hipSetDevice(prev);
@@ -354,109 +344,35 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     return GFDM_HIP_OK;
 }
 
-// *_host calls moving at most this many bytes (inputs + output) go through the pinned, GPU-mapped buffer instead of staged copies
-#ifndef GFDM_ZEROCOPY_MAX_BYTES
-#define GFDM_ZEROCOPY_MAX_BYTES (1024 * 1024)   /* measured crossover with the staged path: 1.2-1.5 MB */
-#endif
-constexpr size_t kZeroCopyMaxBytes = GFDM_ZEROCOPY_MAX_BYTES;
+int status_of(hipError_t e) { return e == hipSuccess ? GFDM_HIP_OK : fail_hip(e, "kernel launch"); }
 
-int ensure_stage(Plan& pl, int slot, size_t elems)
-{
-    if (pl.stage_elems[slot] >= elems) return GFDM_HIP_OK;
-    if (pl.stage[slot]) { (void)hipFree(pl.stage[slot]); pl.stage[slot] = nullptr; pl.stage_elems[slot] = 0; }
-    hipError_t e = hipMalloc(&pl.stage[slot], elems * sizeof(cf));
-    if (e != hipSuccess) { g_last_error = "device staging buffer allocation failed"; return GFDM_HIP_ENOMEM; }
-    pl.stage_elems[slot] = elems;
-    return GFDM_HIP_OK;
-}
-
-// Completion of a small host call without hipStreamSynchronize: a one-lane kernel behind the work on the same stream writes a ticket into
-// pinned host memory and the host spins on it.  Measured on the MI355X box (scratch/probe/host_latency.hip): empty kernel + hipStreamSynchronize
-// 12.2 us, empty kernel + ticket kernel + spin 9.1 us -- the synchronise call, not the launch, is the larger part of a one-block call.
-// Every few thousand spins the stream is queried, so a faulting kernel ends the wait with its error instead of hanging the caller.
-__global__ void k_host_ticket(volatile unsigned* ticket, unsigned value)
-{
-    __threadfence_system();
-    *ticket = value;
-}
-
-hipError_t wait_ticket(Plan& pl, hipStream_t stream)
-{
-    const unsigned want = ++pl.ticket_next;
-    hipLaunchKernelGGL(k_host_ticket, dim3(1), dim3(1), 0, stream, pl.ticket_dev, want);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    volatile unsigned* t = pl.ticket;
-    for (unsigned spins = 1;; ++spins) {
-        if (*t == want) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }      // the results were written before the ticket
-        if ((spins & 0xFFF) == 0) {
-            e = hipStreamQuery(stream);
-            if (e == hipSuccess) return (*t == want) ? hipSuccess : hipStreamSynchronize(stream);
-            if (e != hipErrorNotReady) return e;
-        }
-    }
-}
-
-// Host-pointer convenience path: H2D, launch, D2H, wait.  `launch(out, in0, in1, stream)` enqueues the kernels.
-// Host-pointer convenience path: H2D, launch, D2H, wait.  `launch(out, in0, in1, stream)` enqueues the kernels.
-// Element counts are per call (frames in / demapped symbols out may differ from nblocks * N).
+// Host-pointer path of the block entry points (gfdm_hostpipe.h): operands the GPU can address are used in place, the others bounce through
+// pinned staging sets in chunks, the kernels run across the link.  `launch(out, in0, in1, nb, stream)` enqueues the kernels of nb blocks and
+// returns a status.  Sizes are complex samples per block (frames in / demapped symbols out may differ from the block size); in1 may be read at
+// a stride (the preambles of the self-estimating receivers).
 template <typename Launch>
-int run_host_sized(Plan& pl, float* out, size_t out_elems, const float* in0, size_t in0_elems, const float* in1, size_t in1_elems, Launch launch)
+int run_host_sized(Plan& pl, float* out, size_t out_pb, const float* in0, size_t in0_pb, const float* in1, size_t in1_stride, size_t in1_pb,
+                   int64_t nblocks, Launch launch)
 {
-    if (out == nullptr || in0 == nullptr) return fail(GFDM_HIP_EINVAL, "NULL buffer");
-    if (out_elems == 0 || in0_elems == 0) return GFDM_HIP_OK;
+    if (nblocks < 0 || out == nullptr || in0 == nullptr) return fail(GFDM_HIP_EINVAL, "NULL buffer or negative block count");
+    if (nblocks == 0 || out_pb == 0 || in0_pb == 0) return GFDM_HIP_OK;
     DeviceGuard guard(pl.device);
     if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
-    int rc;
-    const size_t in1_used = in1 ? in1_elems : 0;
-    if ((out_elems + in0_elems + in1_used) * sizeof(cf) <= kZeroCopyMaxBytes) {
-        // small call: through the pinned, GPU-mapped buffer (out | in0 | in1), one launch and one wait, no copy commands
-        const size_t o0 = 0, o1 = (out_elems + 15) & ~(size_t)15, o2 = o1 + ((in0_elems + 15) & ~(size_t)15), total = o2 + ((in1_used + 15) & ~(size_t)15);
-        if (pl.pinned_elems < total) {
-            if (pl.pinned) { (void)hipHostFree(pl.pinned); pl.pinned = nullptr; pl.pinned_elems = 0; }
-            const size_t want = total < 8192 ? 8192 : total;
-            if (hipHostMalloc(reinterpret_cast<void**>(&pl.pinned), want * sizeof(cf), hipHostMallocMapped) == hipSuccess &&
-                hipHostGetDevicePointer(reinterpret_cast<void**>(&pl.pinned_dev), pl.pinned, 0) == hipSuccess) {
-                pl.pinned_elems = want;
-            } else {
-                if (pl.pinned) (void)hipHostFree(pl.pinned);
-                pl.pinned = nullptr;                                  // no mapped host memory: the staged path below serves the call
-            }
-        }
-        if (pl.pinned) {
-            memcpy(pl.pinned + o1, in0, in0_elems * sizeof(cf));
-            if (in1) memcpy(pl.pinned + o2, in1, in1_elems * sizeof(cf));
-            hipError_t e = launch(pl.pinned_dev + o0, pl.pinned_dev + o1, in1 ? pl.pinned_dev + o2 : nullptr, pl.stream);
-            if (e != hipSuccess) return fail_hip(e, "kernel launch");
-            if (!pl.ticket && (hipHostMalloc(reinterpret_cast<void**>(&pl.ticket), 64, hipHostMallocMapped) != hipSuccess ||
-                               hipHostGetDevicePointer(reinterpret_cast<void**>(&pl.ticket_dev), pl.ticket, 0) != hipSuccess)) {
-                if (pl.ticket) (void)hipHostFree(pl.ticket);
-                pl.ticket = nullptr;
-            }
-            if (pl.ticket) { if (pl.ticket_next == 0) *pl.ticket = 0; HIP_TRY(wait_ticket(pl, pl.stream)); }
-            else HIP_TRY(hipStreamSynchronize(pl.stream));
-            memcpy(out, pl.pinned + o0, out_elems * sizeof(cf));
-            return GFDM_HIP_OK;
-        }
-    }
-    if ((rc = ensure_stage(pl, 0, out_elems)) != GFDM_HIP_OK) return rc;
-    if ((rc = ensure_stage(pl, 1, in0_elems)) != GFDM_HIP_OK) return rc;
-    if (in1 && (rc = ensure_stage(pl, 2, in1_elems)) != GFDM_HIP_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(pl.stage[1], in0, in0_elems * sizeof(cf), hipMemcpyHostToDevice, pl.stream));
-    if (in1) HIP_TRY(hipMemcpyAsync(pl.stage[2], in1, in1_elems * sizeof(cf), hipMemcpyHostToDevice, pl.stream));
-    hipError_t e = launch(pl.stage[0], pl.stage[1], in1 ? pl.stage[2] : nullptr, pl.stream);
-    if (e != hipSuccess) return fail_hip(e, "kernel launch");
-    HIP_TRY(hipMemcpyAsync(out, pl.stage[0], out_elems * sizeof(cf), hipMemcpyDeviceToHost, pl.stream));
-    HIP_TRY(hipStreamSynchronize(pl.stream));
-    return GFDM_HIP_OK;
+    const gfdm::HostOperand ops[3] = { { out, out_pb * sizeof(cf), out_pb * sizeof(cf), true },
+                                       { const_cast<float*>(in0), in0_pb * sizeof(cf), in0_pb * sizeof(cf), false },
+                                       { const_cast<float*>(in1), in1_stride * sizeof(cf), in1_pb * sizeof(cf), false } };
+    const int nops = in1 ? 3 : 2;
+    auto fn = [&](void* const* d, int64_t nb, hipStream_t s) {
+        return launch(static_cast<cf*>(d[0]), static_cast<const cf*>(d[1]), nops == 3 ? static_cast<const cf*>(d[2]) : nullptr, nb, s);
+    };
+    return pl.pipe.run(pl.stream, ops, nops, nblocks, fn);
 }
 
 template <typename Launch>
 int run_host(Plan& pl, float* out, const float* in0, const float* in1, int64_t nblocks, Launch launch)
 {
-    if (nblocks < 0 || out == nullptr || in0 == nullptr) return fail(GFDM_HIP_EINVAL, "NULL buffer or negative block count");
-    const size_t elems = (size_t)nblocks * (size_t)pl.dp.N;
-    return run_host_sized(pl, out, elems, in0, elems, in1, elems, launch);
+    const size_t n = (size_t)pl.dp.N;
+    return run_host_sized(pl, out, n, in0, n, in1, n, n, nblocks, launch);
 }
 
 template <typename Launch>
@@ -628,6 +544,7 @@ int gfdm_hip_precompile(int timeslots, int subcarriers, int overlap, unsigned pa
 void gfdm_hip_quiesce(void)
 {
     gfdm::jit_quiesce();
+    gfdm::host_copy_pool_quiesce();
 }
 
 int gfdm_hip_set_ic_matrix_cores(int mode)
@@ -654,7 +571,34 @@ int gfdm_hip_device_count(void)
     return n;
 }
 
-const char* gfdm_hip_version(void) { return "gfdm_hip 0.1 (gfx950)"; }
+// GFDM_BUILD_ID: hash of csrc/*, include/gfdm_hip.h and the compiler flags, written by the Makefile (obj/gfdm_build_id.inc) -- the profiles
+// under profiles/ carry the id of the library they were taken with, and bench.py refuses to quote counters of another build
+#include "gfdm_build_id.inc"
+const char* gfdm_hip_version(void) { return "gfdm_hip 0.4 (gfx950) build " GFDM_BUILD_ID; }
+const char* gfdm_hip_build_id(void) { return GFDM_BUILD_ID; }
+
+int gfdm_hip_register_host(void* ptr, size_t bytes) { return gfdm::host_register(ptr, bytes); }
+int gfdm_hip_unregister_host(void* ptr) { return gfdm::host_unregister(ptr); }
+int gfdm_hip_set_host_pipeline(int mode, int64_t chunk_bytes, int depth, int copy_threads, int kernel_streams)
+{
+    return gfdm::host_pipeline_set(mode, chunk_bytes, depth, copy_threads, kernel_streams);
+}
+int gfdm_hip_get_host_pipeline(int* mode, int64_t* chunk_bytes, int* depth, int* copy_threads, int* kernel_streams)
+{
+    gfdm::host_pipeline_get(mode, chunk_bytes, depth, copy_threads, kernel_streams);
+    return GFDM_HIP_OK;
+}
+int gfdm_hip_host_call_stats(int64_t* chunks, int64_t* chunk_blocks, int64_t* staged_bytes, unsigned* direct_mask, int* mode, int* copy_threads)
+{
+    const gfdm::HostCallStats& st = gfdm::host_last_call();
+    if (chunks) *chunks = st.chunks;
+    if (chunk_blocks) *chunk_blocks = st.chunk_blocks;
+    if (staged_bytes) *staged_bytes = st.staged_bytes;
+    if (direct_mask) *direct_mask = st.direct_mask;
+    if (mode) *mode = st.mode;
+    if (copy_threads) *copy_threads = st.copy_threads;
+    return GFDM_HIP_OK;
+}
 
 // ---- modulator ----
 
@@ -694,8 +638,8 @@ int gfdm_hip_modulator_work_device(gfdm_hip_modulator* m, void* out, const void*
 int gfdm_hip_modulator_work_host(gfdm_hip_modulator* m, float* out, const float* in, int64_t nblocks)
 {
     if (!m) return fail(GFDM_HIP_EINVAL, "NULL handle");
-    return run_host(m->plan, out, in, nullptr, nblocks, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
-        return mod_launch(m->plan, kNoTx, o, i, nblocks, s);
+    return run_host(m->plan, out, in, nullptr, nblocks, [&](cf* o, const cf* i, const cf*, int64_t nb, hipStream_t s) {
+        return status_of(mod_launch(m->plan, kNoTx, o, i, nb, s));
     });
 }
 
@@ -747,8 +691,8 @@ int gfdm_hip_receiver_demodulate_device(gfdm_hip_receiver* r, void* out, const v
 int gfdm_hip_receiver_demodulate_host(gfdm_hip_receiver* r, float* out, const float* in, const float* f_eq, int64_t nblocks)
 {
     if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
-    return run_host(r->plan, out, in, f_eq, nblocks, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
-        return rx_launch(r->plan, kNoIc, gfdm::RX_DEMOD, o, i, e, nblocks, s);
+    return run_host(r->plan, out, in, f_eq, nblocks, [&](cf* o, const cf* i, const cf* e, int64_t nb, hipStream_t s) {
+        return status_of(rx_launch(r->plan, kNoIc, gfdm::RX_DEMOD, o, i, e, nb, s));
     });
 }
 
@@ -764,8 +708,8 @@ int gfdm_hip_receiver_fft_filter_downsample_device(gfdm_hip_receiver* r, void* o
 int gfdm_hip_receiver_fft_filter_downsample_host(gfdm_hip_receiver* r, float* out, const float* in, const float* f_eq, int64_t nblocks)
 {
     if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
-    return run_host(r->plan, out, in, f_eq, nblocks, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
-        return rx_launch(r->plan, kNoIc, gfdm::RX_FD, o, i, e, nblocks, s);
+    return run_host(r->plan, out, in, f_eq, nblocks, [&](cf* o, const cf* i, const cf* e, int64_t nb, hipStream_t s) {
+        return status_of(rx_launch(r->plan, kNoIc, gfdm::RX_FD, o, i, e, nb, s));
     });
 }
 
@@ -780,8 +724,8 @@ int gfdm_hip_receiver_transform_subcarriers_to_td_device(gfdm_hip_receiver* r, v
 int gfdm_hip_receiver_transform_subcarriers_to_td_host(gfdm_hip_receiver* r, float* out, const float* in, int64_t nblocks)
 {
     if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
-    return run_host(r->plan, out, in, nullptr, nblocks, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
-        return gfdm::launch_generic_to_td(r->plan.dp, o, i, nblocks, s);
+    return run_host(r->plan, out, in, nullptr, nblocks, [&](cf* o, const cf* i, const cf*, int64_t nb, hipStream_t s) {
+        return status_of(gfdm::launch_generic_to_td(r->plan.dp, o, i, nb, s));
     });
 }
 
@@ -800,8 +744,8 @@ int gfdm_hip_receiver_cancel_sc_interference_host(gfdm_hip_receiver* r, float* o
 {
     if (!r) return fail(GFDM_HIP_EINVAL, "NULL handle");
     if (!fd_in) return fail(GFDM_HIP_EINVAL, "NULL buffer");
-    return run_host(r->plan, out, td_in, fd_in, nblocks, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
-        return gfdm::launch_generic_cancel(r->plan.dp, o, i, e, nblocks, s);
+    return run_host(r->plan, out, td_in, fd_in, nblocks, [&](cf* o, const cf* i, const cf* e, int64_t nb, hipStream_t s) {
+        return status_of(gfdm::launch_generic_cancel(r->plan.dp, o, i, e, nb, s));
     });
 }
 
@@ -901,8 +845,8 @@ int gfdm_hip_advanced_receiver_work_device(gfdm_hip_advanced_receiver* a, void* 
 int gfdm_hip_advanced_receiver_work_host(gfdm_hip_advanced_receiver* a, float* out, const float* in, const float* f_eq, int64_t nblocks)
 {
     if (!a) return fail(GFDM_HIP_EINVAL, "NULL handle");
-    return run_host(a->plan, out, in, f_eq, nblocks, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
-        return rx_launch(a->plan, a->ic, gfdm::RX_IC, o, i, e, nblocks, s);
+    return run_host(a->plan, out, in, f_eq, nblocks, [&](cf* o, const cf* i, const cf* e, int64_t nb, hipStream_t s) {
+        return status_of(rx_launch(a->plan, a->ic, gfdm::RX_IC, o, i, e, nb, s));
     });
 }
 
@@ -958,9 +902,9 @@ int gfdm_hip_receiver_demodulate_frames_host(gfdm_hip_receiver* r, float* out, c
     gfdm::RxIo io;
     int rc = frame_io_for_call(r->frames, r->plan, noutput_size, io);
     if (rc != GFDM_HIP_OK) return rc;
-    const size_t nb = (size_t)nblocks;
-    return run_host_sized(r->plan, out, nb * io.nout, in, nb * io.in_stride, f_eq, nb * r->plan.dp.N, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
-        return (hipError_t)(gfdm_hip_receiver_demodulate_frames_device(r, o, i, e, noutput_size, nblocks, (void*)s) == GFDM_HIP_OK ? hipSuccess : hipErrorUnknown);
+    const size_t n = (size_t)r->plan.dp.N;
+    return run_host_sized(r->plan, out, (size_t)io.nout, in, (size_t)io.in_stride, f_eq, n, n, nblocks, [&](cf* o, const cf* i, const cf* e, int64_t nb, hipStream_t s) {
+        return gfdm_hip_receiver_demodulate_frames_device(r, o, i, e, noutput_size, nb, (void*)s);
     });
 }
 
@@ -972,9 +916,9 @@ int gfdm_hip_advanced_receiver_work_frames_host(gfdm_hip_advanced_receiver* a, f
     gfdm::RxIo io;
     int rc = frame_io_for_call(a->frames, a->plan, noutput_size, io);
     if (rc != GFDM_HIP_OK) return rc;
-    const size_t nb = (size_t)nblocks;
-    return run_host_sized(a->plan, out, nb * io.nout, in, nb * io.in_stride, f_eq, nb * a->plan.dp.N, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
-        return (hipError_t)(gfdm_hip_advanced_receiver_work_frames_device(a, o, i, e, noutput_size, nblocks, (void*)s) == GFDM_HIP_OK ? hipSuccess : hipErrorUnknown);
+    const size_t n = (size_t)a->plan.dp.N;
+    return run_host_sized(a->plan, out, (size_t)io.nout, in, (size_t)io.in_stride, f_eq, n, n, nblocks, [&](cf* o, const cf* i, const cf* e, int64_t nb, hipStream_t s) {
+        return gfdm_hip_advanced_receiver_work_frames_device(a, o, i, e, noutput_size, nb, (void*)s);
     });
 }
 
@@ -986,14 +930,11 @@ struct gfdm_hip_transmitter {
     Plan plan;
     gfdm::TxParams tx{};          // template: device tables, lengths, shifts; per call: outs, nin, mapped/framed
     void* d_blob = nullptr;       // rank | front | back | preambles
-    cf* stage_out = nullptr;      // staging of the *_host frame outputs
-    size_t stage_out_elems = 0;
     int M = 0, K = 0, A = 0;
     ~gfdm_hip_transmitter()
     {
         DeviceGuard guard(plan.device);
         if (d_blob) (void)hipFree(d_blob);
-        if (stage_out) (void)hipFree(stage_out);
     }
 };
 
@@ -1136,32 +1077,23 @@ int gfdm_hip_transmitter_add_frame_device(gfdm_hip_transmitter* t, void* out, co
     return run_device(t->plan, out, in, nblocks, [&]() { return gfdm::launch_add_frame(t->plan.dp, tx, (const cf*)in, nblocks, (hipStream_t)stream); });
 }
 
-// host-pointer variants: stage, launch, copy back
+// host-pointer variants (gfdm_hostpipe.h): operands = the output ports, then the symbols
 static int tx_host(gfdm_hip_transmitter* t, float* const* outs, int n_outs, size_t out_elems_per_block, const float* in,
-                   size_t in_elems_per_block, int64_t nblocks, const std::function<int(void* const*, const void*, hipStream_t)>& enqueue)
+                   size_t in_elems_per_block, int64_t nblocks, const std::function<int(void* const*, const void*, int64_t, hipStream_t)>& enqueue)
 {
     if (nblocks < 0 || !outs || !in) return fail(GFDM_HIP_EINVAL, "NULL buffer or negative block count");
     if (nblocks == 0) return GFDM_HIP_OK;
     Plan& pl = t->plan;
     DeviceGuard guard(pl.device);
     if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
-    const size_t in_elems = (size_t)nblocks * in_elems_per_block, out_elems = (size_t)nblocks * out_elems_per_block;
-    int rc = ensure_stage(pl, 1, in_elems > 0 ? in_elems : 1);
-    if (rc != GFDM_HIP_OK) return rc;
-    if (t->stage_out_elems < out_elems * n_outs) {
-        if (t->stage_out) (void)hipFree(t->stage_out);
-        t->stage_out = nullptr; t->stage_out_elems = 0;
-        if (hipMalloc(&t->stage_out, out_elems * n_outs * sizeof(cf)) != hipSuccess) return fail(GFDM_HIP_ENOMEM, "device staging buffer allocation failed");
-        t->stage_out_elems = out_elems * n_outs;
+    gfdm::HostOperand ops[gfdm::TX_MAX_PORTS + 1];
+    for (int i = 0; i < n_outs; ++i) {
+        if (!outs[i]) return fail(GFDM_HIP_EINVAL, "NULL output port");
+        ops[i] = gfdm::HostOperand{ outs[i], out_elems_per_block * sizeof(cf), out_elems_per_block * sizeof(cf), true };
     }
-    HIP_TRY(hipMemcpyAsync(pl.stage[1], in, in_elems * sizeof(cf), hipMemcpyHostToDevice, pl.stream));
-    void* dev_outs[gfdm::TX_MAX_PORTS];
-    for (int i = 0; i < n_outs; ++i) dev_outs[i] = t->stage_out + (size_t)i * out_elems;
-    rc = enqueue(dev_outs, pl.stage[1], pl.stream);
-    if (rc != GFDM_HIP_OK) return rc;
-    for (int i = 0; i < n_outs; ++i) HIP_TRY(hipMemcpyAsync(outs[i], dev_outs[i], out_elems * sizeof(cf), hipMemcpyDeviceToHost, pl.stream));
-    HIP_TRY(hipStreamSynchronize(pl.stream));
-    return GFDM_HIP_OK;
+    ops[n_outs] = gfdm::HostOperand{ const_cast<float*>(in), in_elems_per_block * sizeof(cf), in_elems_per_block * sizeof(cf), false };
+    auto fn = [&](void* const* d, int64_t nb, hipStream_t s) { return enqueue(d, d[n_outs], nb, s); };
+    return pl.pipe.run(pl.stream, ops, n_outs + 1, nblocks, fn);
 }
 
 int gfdm_hip_transmitter_work_host(gfdm_hip_transmitter* t, float* const* outs, int n_outs, const float* in, int ninput_size, int64_t nblocks)
@@ -1170,8 +1102,8 @@ int gfdm_hip_transmitter_work_host(gfdm_hip_transmitter* t, float* const* outs, 
     if (n_outs < 1 || n_outs > t->tx.nports) return fail(GFDM_HIP_EINVAL, "n_outs must be between 1 and the number of cyclic shifts");
     int rc = tx_check_nin(t, ninput_size);
     if (rc != GFDM_HIP_OK) return rc;
-    return tx_host(t, outs, n_outs, (size_t)t->tx.F, in, (size_t)ninput_size, nblocks, [&](void* const* d_outs, const void* d_in, hipStream_t s) {
-        return gfdm_hip_transmitter_work_device(t, d_outs, n_outs, d_in, ninput_size, nblocks, (void*)s);
+    return tx_host(t, outs, n_outs, (size_t)t->tx.F, in, (size_t)ninput_size, nblocks, [&](void* const* d_outs, const void* d_in, int64_t nb, hipStream_t s) {
+        return gfdm_hip_transmitter_work_device(t, d_outs, n_outs, d_in, ninput_size, nb, (void*)s);
     });
 }
 
@@ -1181,8 +1113,8 @@ int gfdm_hip_transmitter_modulate_host(gfdm_hip_transmitter* t, float* out, cons
     int rc = tx_check_nin(t, ninput_size);
     if (rc != GFDM_HIP_OK) return rc;
     float* outs[1] = { out };
-    return tx_host(t, outs, 1, (size_t)t->plan.dp.N, in, (size_t)ninput_size, nblocks, [&](void* const* d_outs, const void* d_in, hipStream_t s) {
-        return gfdm_hip_transmitter_modulate_device(t, d_outs[0], d_in, ninput_size, nblocks, (void*)s);
+    return tx_host(t, outs, 1, (size_t)t->plan.dp.N, in, (size_t)ninput_size, nblocks, [&](void* const* d_outs, const void* d_in, int64_t nb, hipStream_t s) {
+        return gfdm_hip_transmitter_modulate_device(t, d_outs[0], d_in, ninput_size, nb, (void*)s);
     });
 }
 
@@ -1190,8 +1122,8 @@ int gfdm_hip_transmitter_add_frame_host(gfdm_hip_transmitter* t, float* out, con
 {
     if (!t) return fail(GFDM_HIP_EINVAL, "NULL handle");
     float* outs[1] = { out };
-    return tx_host(t, outs, 1, (size_t)t->tx.F, in, (size_t)t->plan.dp.N, nblocks, [&](void* const* d_outs, const void* d_in, hipStream_t s) {
-        return gfdm_hip_transmitter_add_frame_device(t, d_outs[0], d_in, cyclic_shift, nblocks, (void*)s);
+    return tx_host(t, outs, 1, (size_t)t->tx.F, in, (size_t)t->plan.dp.N, nblocks, [&](void* const* d_outs, const void* d_in, int64_t nb, hipStream_t s) {
+        return gfdm_hip_transmitter_add_frame_device(t, d_outs[0], d_in, cyclic_shift, nb, (void*)s);
     });
 }
 
@@ -1253,13 +1185,13 @@ int est_run_host(gfdm_hip_channel_estimator* c, int in_stage, int out_stage, flo
 {
     if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
     if (nframes < 0) return fail(GFDM_HIP_EINVAL, "negative frame count");
-    const size_t nout = (size_t)nframes * est_stage_elems(c->ep, out_stage), nin = (size_t)nframes * est_stage_elems(c->ep, in_stage);
-    return run_host_sized(c->plan, out, nout, in, nin, nullptr, 0, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
+    const size_t nout = est_stage_elems(c->ep, out_stage), nin = est_stage_elems(c->ep, in_stage);
+    return run_host_sized(c->plan, out, nout, in, nin, nullptr, 0, 0, nframes, [&](cf* o, const cf* i, const cf*, int64_t nf, hipStream_t s) {
         if (c->plan.current_family() == gfdm::FAMILY_ROWLANE && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
-            return gfdm::launch_rowlane_estimate(c->ep, o, i, nframes, s);
+            return status_of(gfdm::launch_rowlane_estimate(c->ep, o, i, nf, s));
         if (c->plan.family == gfdm::FAMILY_ROWLANE_JIT && in_stage == gfdm::EST_RX_PREAMBLE && out_stage == gfdm::EST_FRAME)
-            return gfdm::jit_launch_estimate(&c->plan.jit, c->ep, o, i, nframes, s);
-        return gfdm::launch_estimate(c->ep, in_stage, out_stage, o, i, nframes, s);
+            return status_of(gfdm::jit_launch_estimate(&c->plan.jit, c->ep, o, i, nf, s));
+        return status_of(gfdm::launch_estimate(c->ep, in_stage, out_stage, o, i, nf, s));
     });
 }
 
@@ -1413,9 +1345,9 @@ int gfdm_hip_channel_estimator_prepare_for_zf_host(gfdm_hip_channel_estimator* c
 {
     if (!c) return fail(GFDM_HIP_EINVAL, "NULL handle");
     if (nframes < 0) return fail(GFDM_HIP_EINVAL, "negative frame count");
-    const size_t n = (size_t)nframes * c->ep.M * c->ep.K;
-    return run_host_sized(c->plan, transformed_frame, n, frame_estimate, n, nullptr, 0, [&](cf* o, const cf* i, const cf*, hipStream_t s) {
-        return gfdm::launch_prepare_for_zf(o, i, (int64_t)n, s);
+    const size_t n = (size_t)c->ep.M * c->ep.K;
+    return run_host_sized(c->plan, transformed_frame, n, frame_estimate, n, nullptr, 0, 0, nframes, [&](cf* o, const cf* i, const cf*, int64_t nf, hipStream_t s) {
+        return status_of(gfdm::launch_prepare_for_zf(o, i, nf * (int64_t)n, s));
     });
 }
 
@@ -1437,20 +1369,13 @@ int gfdm_hip_channel_estimator_estimate_snr_host(gfdm_hip_channel_estimator* c, 
     Plan& pl = c->plan;
     DeviceGuard guard(pl.device);
     if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
-    const size_t A = (size_t)c->ep.A, nin = (size_t)nframes * 2 * c->ep.K;
-    const size_t nfloats = (size_t)nframes * (A + 1);                 // snr[nframes] | cnrs[nframes][A], staged as floats
-    int rc;
-    if ((rc = ensure_stage(pl, 0, (nfloats + 1) / 2)) != GFDM_HIP_OK) return rc;
-    if ((rc = ensure_stage(pl, 1, nin)) != GFDM_HIP_OK) return rc;
-    float* d_snr = reinterpret_cast<float*>(pl.stage[0]);
-    float* d_cnrs = d_snr + nframes;
-    HIP_TRY(hipMemcpyAsync(pl.stage[1], rx_preamble, nin * sizeof(cf), hipMemcpyHostToDevice, pl.stream));
-    hipError_t e = gfdm::launch_estimate_snr(c->ep, d_snr, d_cnrs, pl.stage[1], nframes, pl.stream);
-    if (e != hipSuccess) return fail_hip(e, "kernel launch");
-    HIP_TRY(hipMemcpyAsync(snr_lin, d_snr, (size_t)nframes * sizeof(float), hipMemcpyDeviceToHost, pl.stream));
-    HIP_TRY(hipMemcpyAsync(cnrs, d_cnrs, (size_t)nframes * A * sizeof(float), hipMemcpyDeviceToHost, pl.stream));
-    HIP_TRY(hipStreamSynchronize(pl.stream));
-    return GFDM_HIP_OK;
+    const size_t A = (size_t)c->ep.A, npre = 2 * (size_t)c->ep.K * sizeof(cf);
+    const gfdm::HostOperand ops[3] = { { snr_lin, sizeof(float), sizeof(float), true }, { cnrs, A * sizeof(float), A * sizeof(float), true },
+                                       { const_cast<float*>(rx_preamble), npre, npre, false } };
+    auto fn = [&](void* const* d, int64_t nf, hipStream_t s) {
+        return status_of(gfdm::launch_estimate_snr(c->ep, static_cast<float*>(d[0]), static_cast<float*>(d[1]), static_cast<const cf*>(d[2]), nf, s));
+    };
+    return pl.pipe.run(pl.stream, ops, 3, nframes, fn);
 }
 
 }  // extern "C"
@@ -1504,11 +1429,8 @@ int est_call_host(Plan& pl, const gfdm::RxIo& io, const gfdm::EstPlan& ep, float
 {
     if (nblocks < 0) return fail(GFDM_HIP_EINVAL, "negative block count");
     if (!rx_preamble) return fail(GFDM_HIP_EINVAL, "NULL buffer");
-    const size_t nb = (size_t)nblocks;
-    const size_t npre = nb ? (nb - 1) * (size_t)ep.pre_stride + 2 * (size_t)ep.K : 0;
-    return run_host_sized(pl, out, nb * io.nout, in, nb * io.in_stride, rx_preamble, npre, [&](cf* o, const cf* i, const cf* e, hipStream_t s) {
-        return (hipError_t)(call(o, i, e, (void*)s) == GFDM_HIP_OK ? hipSuccess : hipErrorUnknown);
-    });
+    return run_host_sized(pl, out, (size_t)io.nout, in, (size_t)io.in_stride, rx_preamble, (size_t)ep.pre_stride, 2 * (size_t)ep.K, nblocks,
+                          [&](cf* o, const cf* i, const cf* e, int64_t nb, hipStream_t s) { return call(o, i, e, nb, (void*)s); });
 }
 
 }  // namespace
@@ -1596,8 +1518,8 @@ int gfdm_hip_receiver_demodulate_estimated_host(gfdm_hip_receiver* r, float* out
     gfdm::EstPlan ep;
     int rc = est_call_io(r->frames, r->plan, r->est, preamble_stride, noutput_size, io, ep);
     if (rc != GFDM_HIP_OK) return rc;
-    return est_call_host(r->plan, io, ep, out, in, rx_preamble, nblocks, [&](cf* o, const cf* i, const cf* e, void* s) {
-        return gfdm_hip_receiver_demodulate_estimated_device(r, o, i, e, preamble_stride, noutput_size, nblocks, s);
+    return est_call_host(r->plan, io, ep, out, in, rx_preamble, nblocks, [&](cf* o, const cf* i, const cf* e, int64_t nb, void* s) {
+        return gfdm_hip_receiver_demodulate_estimated_device(r, o, i, e, preamble_stride, noutput_size, nb, s);
     });
 }
 
@@ -1609,8 +1531,8 @@ int gfdm_hip_advanced_receiver_work_estimated_host(gfdm_hip_advanced_receiver* a
     gfdm::EstPlan ep;
     int rc = est_call_io(a->frames, a->plan, a->est, preamble_stride, noutput_size, io, ep);
     if (rc != GFDM_HIP_OK) return rc;
-    return est_call_host(a->plan, io, ep, out, in, rx_preamble, nblocks, [&](cf* o, const cf* i, const cf* e, void* s) {
-        return gfdm_hip_advanced_receiver_work_estimated_device(a, o, i, e, preamble_stride, noutput_size, nblocks, s);
+    return est_call_host(a->plan, io, ep, out, in, rx_preamble, nblocks, [&](cf* o, const cf* i, const cf* e, int64_t nb, void* s) {
+        return gfdm_hip_advanced_receiver_work_estimated_device(a, o, i, e, preamble_stride, noutput_size, nb, s);
     });
 }
 

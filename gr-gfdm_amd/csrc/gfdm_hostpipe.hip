@@ -1,0 +1,481 @@
+// Host-buffer batch path (gfdm_hostpipe.h): operand classification, chunked bounce through pinned staging sets, completion tickets,
+// the copy-thread pool.  No GFDM arithmetic here and no CPU compute path: the kernels of a call are enqueued by the caller's `launch`.
+#include "gfdm_hostpipe.h"
+#include "../../include/gfdm_hip.h"
+#include "gfdm_plan.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace gfdm {
+
+namespace {
+
+// how the bytes cross the link: 0 under the kernels' own accesses to host memory, 1 copy engines + device staging, 2 inputs under the
+// kernel's reads and outputs by copy engine, 3 the reverse (HostPipe::run)
+std::atomic<int> g_mode{ 0 };
+// bytes of all staged operands per chunk; 0 = automatic (one chunk up to kSingleChunkMax, else total / 8 within [kAutoMin, kAutoMax]:
+// profiles/r04/host_path_sweep.txt -- 4 MiB chunks are best for a 4096-block call, 16 MiB for 65 536 blocks)
+std::atomic<int64_t> g_chunk_bytes{ 0 };
+std::atomic<int> g_depth{ 3 };
+std::atomic<int> g_copy_threads{ 3 };
+std::atomic<int> g_kernel_streams{ 2 };         // mode 0: chunks alternate between this many streams (1 or 2)
+
+constexpr size_t kSingleChunkMax = 1u << 20;    // a call that stages at most this much is one chunk (measured crossover 1.2-1.5 MB, round 2)
+constexpr size_t kAutoMin = 512u << 10, kAutoMax = 16u << 20;
+constexpr size_t kAlign = 256;
+constexpr size_t kSliceBytes = 256u << 10;      // unit of work of the copy pool
+constexpr size_t kPoolMinBytes = 512u << 10;    // smaller copy jobs stay on the calling thread
+constexpr int64_t kMaxLaunchBlocks = 1 << 30;
+constexpr int kTicketStride = 16;               // one 64-byte line per completion ticket
+
+size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
+
+__global__ void k_host_ticket(volatile unsigned* ticket, unsigned value)
+{
+    __threadfence_system();
+    *ticket = value;
+}
+
+// ---- copy pool: the bounce copies of one chunk, cut into slices, shared between the calling thread and a few pool threads -------------
+struct Slice { char* dst; const char* src; size_t n; };
+struct CopyJob {
+    std::vector<Slice> slices;
+    std::atomic<size_t> next{ 0 }, done{ 0 };
+    void work()
+    {
+        const size_t n = slices.size();
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) return;
+            memcpy(slices[i].dst, slices[i].src, slices[i].n);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+};
+
+class CopyPool {
+public:
+    // runs the job on the calling thread and up to `helpers` pool threads; returns when every slice is copied
+    int run(const std::shared_ptr<CopyJob>& job, int helpers)
+    {
+        int used = 0;
+        if (helpers > 0) {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!stopping_) {
+                while ((int)threads_.size() < helpers && (int)threads_.size() < 16) threads_.emplace_back([this] { loop(); });
+                used = (int)threads_.size() < helpers ? (int)threads_.size() : helpers;
+                current_ = job;
+                wanted_ = used;
+                gen_.fetch_add(1, std::memory_order_release);
+            }
+        }
+        if (used) cv_.notify_all();
+        job->work();
+        const size_t n = job->slices.size();
+        while (job->done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+        return used;
+    }
+    void quiesce()
+    {
+        std::vector<std::thread> th;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stopping_ = true;
+            gen_.fetch_add(1, std::memory_order_release);
+            th.swap(threads_);
+        }
+        cv_.notify_all();
+        for (auto& t : th) t.join();
+        std::lock_guard<std::mutex> lk(mu_);
+        stopping_ = false;
+        current_.reset();
+    }
+    ~CopyPool() { quiesce(); }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::thread> threads_;
+    std::shared_ptr<CopyJob> current_;
+    std::atomic<uint64_t> gen_{ 0 };
+    int wanted_ = 0;
+    bool stopping_ = false;
+
+    void loop()
+    {
+        uint64_t seen = gen_.load(std::memory_order_acquire);
+        for (;;) {
+            // chunks of one call follow each other within tens of microseconds: spin briefly before going to sleep
+            for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+            std::shared_ptr<CopyJob> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                seen = gen_.load(std::memory_order_acquire);
+                if (stopping_) return;
+                if (wanted_ > 0) { --wanted_; job = current_; }
+            }
+            if (job) job->work();
+        }
+    }
+};
+
+CopyPool g_pool;
+
+thread_local HostCallStats t_stats;
+
+}  // namespace
+
+int host_pipeline_set(int mode, int64_t chunk_bytes, int depth, int copy_threads, int kernel_streams)
+{
+    if (mode > 3 || depth == 0 || depth > HOST_MAX_DEPTH || copy_threads > 16 || kernel_streams == 0 || kernel_streams > 2)
+        return api_fail(GFDM_HIP_EINVAL, "host pipeline: mode 0..3, depth 1..4, copy threads 0..16, kernel streams 1..2");
+    if (kernel_streams > 0) g_kernel_streams.store(kernel_streams);
+    if (mode >= 0) g_mode.store(mode);
+    if (chunk_bytes >= 0) g_chunk_bytes.store(chunk_bytes);
+    if (depth > 0) g_depth.store(depth);
+    if (copy_threads >= 0) g_copy_threads.store(copy_threads);
+    return GFDM_HIP_OK;
+}
+
+void host_pipeline_get(int* mode, int64_t* chunk_bytes, int* depth, int* copy_threads, int* kernel_streams)
+{
+    if (kernel_streams) *kernel_streams = g_kernel_streams.load();
+    if (mode) *mode = g_mode.load();
+    if (chunk_bytes) *chunk_bytes = g_chunk_bytes.load();
+    if (depth) *depth = g_depth.load();
+    if (copy_threads) *copy_threads = g_copy_threads.load();
+}
+
+HostCallStats& host_last_call() { return t_stats; }
+void host_copy_pool_quiesce() { g_pool.quiesce(); }
+
+int host_register(void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return api_fail(GFDM_HIP_EINVAL, "register_host: NULL pointer or zero size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return api_fail(GFDM_HIP_ENODEV, "no HIP device available");
+    hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    if (e != hipSuccess) { (void)hipGetLastError(); return api_fail_hip(e, "hipHostRegister"); }
+    return GFDM_HIP_OK;
+}
+
+int host_unregister(void* p)
+{
+    if (!p) return api_fail(GFDM_HIP_EINVAL, "unregister_host: NULL pointer");
+    hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return api_fail_hip(e, "hipHostUnregister"); }
+    return GFDM_HIP_OK;
+}
+
+void HostPipe::release()
+{
+    for (Set& s : sets_) {
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.dcopy) (void)hipFree(s.dcopy);
+        s = Set{};
+    }
+    if (ticket_) (void)hipHostFree(ticket_);
+    ticket_ = ticket_dev_ = nullptr;
+    if (have_events_)
+        for (int i = 0; i < HOST_MAX_DEPTH; ++i) { (void)hipEventDestroy(ev_in_[i]); (void)hipEventDestroy(ev_k_[i]); }
+    have_events_ = false;
+    if (s_in_) (void)hipStreamDestroy(s_in_);
+    if (s_out_) (void)hipStreamDestroy(s_out_);
+    if (s_b_) (void)hipStreamDestroy(s_b_);
+    s_in_ = s_out_ = s_b_ = nullptr;
+}
+
+int HostPipe::ensure_set(int i, size_t host_bytes, size_t dev_bytes)
+{
+    Set& s = sets_[i];
+    if (s.cap < host_bytes) {
+        if (s.host) (void)hipHostFree(s.host);
+        s.host = s.dev = nullptr;
+        size_t want = host_bytes < (64u << 10) ? (64u << 10) : host_bytes;
+        if (want < 2 * s.cap) want = 2 * s.cap;
+        s.cap = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&s.host), want, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&s.dev), s.host, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (s.host) (void)hipHostFree(s.host);
+            s.host = s.dev = nullptr;
+            return api_fail(GFDM_HIP_ENOMEM, "pinned staging buffer allocation failed");
+        }
+        s.cap = want;
+    }
+    if (s.dcap < dev_bytes) {
+        if (s.dcopy) (void)hipFree(s.dcopy);
+        s.dcopy = nullptr;
+        size_t want = dev_bytes < (64u << 10) ? (64u << 10) : dev_bytes;
+        if (want < 2 * s.dcap) want = 2 * s.dcap;
+        s.dcap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&s.dcopy), want) != hipSuccess) { (void)hipGetLastError(); return api_fail(GFDM_HIP_ENOMEM, "device staging buffer allocation failed"); }
+        s.dcap = want;
+    }
+    return GFDM_HIP_OK;
+}
+
+int HostPipe::ensure_ticket()
+{
+    if (ticket_) return GFDM_HIP_OK;
+    if (hipHostMalloc(reinterpret_cast<void**>(&ticket_), kTicketStride * sizeof(unsigned) * HOST_MAX_DEPTH, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&ticket_dev_), ticket_, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ticket_) (void)hipHostFree(ticket_);
+        ticket_ = ticket_dev_ = nullptr;
+        return api_fail(GFDM_HIP_ENOMEM, "completion ticket allocation failed");
+    }
+    for (int i = 0; i < HOST_MAX_DEPTH; ++i) ticket_[i * kTicketStride] = 0;
+    ticket_next_ = 0;
+    return GFDM_HIP_OK;
+}
+
+int HostPipe::ensure_copy_engines()
+{
+    if (!s_in_ && hipStreamCreateWithFlags(&s_in_, hipStreamNonBlocking) != hipSuccess) return api_fail(GFDM_HIP_EHIP, "hipStreamCreate");
+    if (!s_out_ && hipStreamCreateWithFlags(&s_out_, hipStreamNonBlocking) != hipSuccess) return api_fail(GFDM_HIP_EHIP, "hipStreamCreate");
+    if (!have_events_) {
+        for (int i = 0; i < HOST_MAX_DEPTH; ++i)
+            if (hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_k_[i], hipEventDisableTiming) != hipSuccess)
+                return api_fail(GFDM_HIP_EHIP, "hipEventCreate");
+        have_events_ = true;
+    }
+    return GFDM_HIP_OK;
+}
+
+// Completion without hipStreamSynchronize: a one-lane kernel behind the work on the same stream writes a ticket into pinned host memory and
+// the host spins on it (scratch/probe/host_latency.hip: empty kernel + hipStreamSynchronize 12.2 us, + ticket kernel + spin 9.1 us).  Every
+// few thousand spins the stream is queried, so a faulting kernel ends the wait with its error instead of hanging the caller.
+hipError_t HostPipe::post_ticket(hipStream_t s, int slot, unsigned value)
+{
+    hipLaunchKernelGGL(k_host_ticket, dim3(1), dim3(1), 0, s, ticket_dev_ + slot * kTicketStride, value);
+    return hipGetLastError();
+}
+
+hipError_t HostPipe::wait_ticket(hipStream_t s, int slot, unsigned value)
+{
+    volatile unsigned* t = ticket_ + slot * kTicketStride;
+    for (unsigned spins = 1;; ++spins) {
+        if ((int)(*t - value) >= 0) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }   // the results were written before the ticket
+        if ((spins & 0xFFF) == 0) {
+            hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) return ((int)(*t - value) >= 0) ? hipSuccess : hipStreamSynchronize(s);
+            if (e != hipErrorNotReady) return e;
+        }
+    }
+}
+
+int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t nblocks, HostLaunchRef launch)
+{
+    HostCallStats& st = t_stats;
+    st = HostCallStats{};
+    if (nops < 1 || nops > HOST_MAX_OPERANDS || nblocks < 0) return api_fail(GFDM_HIP_EINVAL, "bad operand list or negative block count");
+    if (nblocks == 0) return GFDM_HIP_OK;
+    const int mode = g_mode.load();
+    st.mode = mode;
+
+    // ---- which operands can the GPU address as they are? ---------------------------------------------------------------------------
+    bool direct[HOST_MAX_OPERANDS];
+    bool host_mem[HOST_MAX_OPERANDS];                  // not device / managed memory: the copy engines can serve it
+    char* direct_dev[HOST_MAX_OPERANDS];
+    size_t extent[HOST_MAX_OPERANDS];
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    for (int i = 0; i < nops; ++i) {
+        const HostOperand& o = ops[i];
+        extent[i] = o.last ? (size_t)(nblocks - 1) * o.stride + o.last : 0;
+        direct[i] = false;
+        host_mem[i] = true;
+        direct_dev[i] = static_cast<char*>(o.host);
+        if (extent[i] == 0) { direct[i] = true; continue; }           // nothing to move: the kernel never touches it
+        if (!o.host) return api_fail(GFDM_HIP_EINVAL, "NULL buffer");
+        hipPointerAttribute_t a0{}, a1{};
+        if (hipPointerGetAttributes(&a0, o.host) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (a0.type != hipMemoryTypeHost && a0.type != hipMemoryTypeDevice && a0.type != hipMemoryTypeManaged) continue;
+        if (hipPointerGetAttributes(&a1, static_cast<char*>(o.host) + extent[i] - 1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (a1.type != a0.type) continue;                             // only partly registered: bounce it
+        if (a0.type == hipMemoryTypeDevice && a0.device != cur_dev) return api_fail(GFDM_HIP_EINVAL, "buffer lives in the memory of another GPU");
+        if (!a0.devicePointer) continue;
+        direct[i] = true;
+        host_mem[i] = a0.type == hipMemoryTypeHost;
+        direct_dev[i] = static_cast<char*>(a0.devicePointer);
+    }
+    // an output handed over in place must not overlap another in-place operand (the kernels assume distinct buffers): bounce it instead
+    for (int i = 0; i < nops; ++i) {
+        if (!direct[i] || !ops[i].write || extent[i] == 0) continue;
+        const char* b0 = static_cast<const char*>(ops[i].host);
+        for (int j = 0; j < nops; ++j) {
+            if (j == i || !direct[j] || extent[j] == 0) continue;
+            const char* b1 = static_cast<const char*>(ops[j].host);
+            if (b0 < b1 + extent[j] && b1 < b0 + extent[i]) { direct[i] = false; break; }
+        }
+    }
+    size_t per_block = 0, total_staged = 0;
+    for (int i = 0; i < nops; ++i) {
+        if (direct[i]) { st.direct_mask |= 1u << i; continue; }
+        per_block += ops[i].stride ? ops[i].stride : ops[i].last;
+        total_staged += extent[i];
+    }
+    st.staged_bytes = (int64_t)total_staged;
+
+    int rc = ensure_ticket();
+    if (rc != GFDM_HIP_OK) return rc;
+
+    // ---- routes ------------------------------------------------------------------------------------------------------------------------------
+    // A kernel reads its blocks and then writes them; a launch whose workgroups are all resident at once (a few thousand blocks) therefore drives
+    // the link in ONE direction at a time (57 GB/s of the 96 GB/s both directions carry together), and launches on one stream do not overlap.
+    // Per operand the bytes cross the link either under the kernel's own accesses ("zero copy", ZC) or on a copy engine to / from device staging
+    // (CE).  mode 0: everything ZC; 1: everything CE; 2: inputs ZC, outputs CE -- the copy engine writes chunk c back while the kernel of chunk
+    // c + 1 reads, i.e. both directions busy; 3: inputs CE, outputs ZC.  Device / managed memory handed to a *_host call is always used as is.
+    bool ce[HOST_MAX_OPERANDS];
+    bool any_ce = false;
+    for (int i = 0; i < nops; ++i) {
+        ce[i] = extent[i] != 0 && host_mem[i] && (mode == 1 || (mode == 2 && ops[i].write) || (mode == 3 && !ops[i].write));
+        any_ce = any_ce || ce[i];
+    }
+    const bool all_direct = total_staged == 0;
+    const bool one_launch = all_direct && !any_ce;      // kernels on the caller's memory: a single launch mixes the directions by itself
+    size_t per_block_all = 0, total_all = 0;
+    for (int i = 0; i < nops; ++i) { per_block_all += ops[i].stride ? ops[i].stride : ops[i].last; total_all += extent[i]; }
+    const size_t plan_per_block = all_direct ? per_block_all : per_block, plan_total = all_direct ? total_all : total_staged;
+    size_t chunk_bytes = (size_t)g_chunk_bytes.load();
+    int64_t chunk_blocks;
+    if (one_launch) chunk_blocks = nblocks;
+    else if (chunk_bytes == 0) {
+        if (plan_total <= kSingleChunkMax) chunk_blocks = nblocks;
+        else {
+            chunk_bytes = plan_total / 8;
+            chunk_bytes = chunk_bytes < kAutoMin ? kAutoMin : chunk_bytes > kAutoMax ? kAutoMax : chunk_bytes;
+            chunk_blocks = (int64_t)(chunk_bytes / (plan_per_block ? plan_per_block : 1));
+        }
+    } else {
+        chunk_blocks = (int64_t)(chunk_bytes / (plan_per_block ? plan_per_block : 1));
+    }
+    if (chunk_blocks < 1) chunk_blocks = 1;
+    if (chunk_blocks > nblocks) chunk_blocks = nblocks;
+    if (chunk_blocks > kMaxLaunchBlocks) chunk_blocks = kMaxLaunchBlocks;
+    const int64_t nchunks = (nblocks + chunk_blocks - 1) / chunk_blocks;
+    auto chunk_nb = [&](int64_t c) { const int64_t c0 = c * chunk_blocks; return nblocks - c0 < chunk_blocks ? nblocks - c0 : chunk_blocks; };
+    auto chunk_size = [&](int i, int64_t nb) { return (size_t)(nb - 1) * ops[i].stride + ops[i].last; };
+    st.chunk_blocks = chunk_blocks;
+    const bool two_streams = !any_ce && nchunks >= 2 && g_kernel_streams.load() >= 2;
+    if (two_streams && (rc = ensure_second_stream()) != GFDM_HIP_OK) return rc;
+    auto kernel_stream = [&](int64_t c) { return (two_streams && (c & 1)) ? s_b_ : stream; };
+    auto drain = [&]() {      // error path: nothing may touch the staging sets or the caller's memory after we return
+        (void)hipStreamSynchronize(stream);
+        if (s_b_) (void)hipStreamSynchronize(s_b_);
+        if (s_in_) (void)hipStreamSynchronize(s_in_);
+        if (s_out_) (void)hipStreamSynchronize(s_out_);
+    };
+
+    // ---- staging sets: pinned host memory for the bounced operands, device memory for the copy-engine routed ones ---------------------------
+    int depth = g_depth.load();
+    if (depth > nchunks) depth = (int)nchunks;
+    st.depth = depth;
+    size_t off_host[HOST_MAX_OPERANDS] = {}, off_dev[HOST_MAX_OPERANDS] = {};
+    size_t host_bytes = 0, dev_bytes = 0;
+    bool ce_in = false, ce_out = false;
+    for (int i = 0; i < nops; ++i) {
+        const size_t sz = extent[i] ? align_up(chunk_size(i, chunk_blocks)) : 0;
+        if (!direct[i]) { off_host[i] = host_bytes; host_bytes += sz; }
+        if (ce[i]) { off_dev[i] = dev_bytes; dev_bytes += sz; (ops[i].write ? ce_out : ce_in) = true; }
+    }
+    for (int s = 0; s < depth; ++s)
+        if ((host_bytes || dev_bytes) && (rc = ensure_set(s, host_bytes, dev_bytes)) != GFDM_HIP_OK) return rc;
+    if (any_ce && (rc = ensure_copy_engines()) != GFDM_HIP_OK) return rc;
+    const int helpers = g_copy_threads.load();
+    auto done_stream = [&](int64_t c) { return ce_out ? s_out_ : kernel_stream(c); };
+    unsigned want[HOST_MAX_DEPTH] = {};
+
+    std::shared_ptr<CopyJob> job;
+    auto job_add = [&](char* dst, const char* src, size_t n) {
+        if (!job) job = std::make_shared<CopyJob>();
+        for (size_t o = 0; o < n; o += kSliceBytes) job->slices.push_back(Slice{ dst + o, src + o, n - o < kSliceBytes ? n - o : kSliceBytes });
+    };
+    auto user_ptr = [&](int i, int64_t c) { return static_cast<char*>(ops[i].host) + (size_t)(c * chunk_blocks) * ops[i].stride; };
+    auto add_copy_out = [&](int64_t c) {
+        const Set& s = sets_[c % depth];
+        for (int i = 0; i < nops; ++i)
+            if (!direct[i] && ops[i].write) job_add(user_ptr(i, c), s.host + off_host[i], chunk_size(i, chunk_nb(c)));
+    };
+    auto add_copy_in = [&](int64_t c) {
+        const Set& s = sets_[c % depth];
+        for (int i = 0; i < nops; ++i)
+            if (!direct[i] && !ops[i].write) job_add(s.host + off_host[i], user_ptr(i, c), chunk_size(i, chunk_nb(c)));
+    };
+    auto run_job = [&]() {
+        if (!job) return;
+        size_t bytes = 0;
+        for (const Slice& sl : job->slices) bytes += sl.n;
+        if (helpers > 0 && bytes >= kPoolMinBytes) {
+            const int used = g_pool.run(job, helpers);
+            if (used > st.copy_threads) st.copy_threads = used;
+        } else {
+            for (const Slice& sl : job->slices) memcpy(sl.dst, sl.src, sl.n);
+        }
+        job.reset();
+    };
+
+    int64_t retired = 0;                       // chunks [0, retired) are back in the caller's memory
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const int si = (int)(c % depth);
+        Set& s = sets_[si];
+        if (c >= depth) {                      // the set is still in use by chunk c - depth: wait for it, take its outputs with this chunk's inputs
+            hipError_t e = wait_ticket(done_stream(c - depth), si, want[si]);
+            if (e != hipSuccess) { drain(); return api_fail_hip(e, "host call"); }
+            add_copy_out(c - depth);
+            retired = c - depth + 1;
+        }
+        add_copy_in(c);
+        run_job();
+        const int64_t nb = chunk_nb(c);
+        hipStream_t ks = kernel_stream(c);
+        void* dev[HOST_MAX_OPERANDS];
+        for (int i = 0; i < nops; ++i)
+            dev[i] = ce[i] ? s.dcopy + off_dev[i] : direct[i] ? direct_dev[i] + (size_t)(c * chunk_blocks) * ops[i].stride : s.dev + off_host[i];
+        hipError_t e = hipSuccess;
+        if (ce_in) {
+            for (int i = 0; i < nops && e == hipSuccess; ++i)
+                if (ce[i] && !ops[i].write)
+                    e = hipMemcpyAsync(s.dcopy + off_dev[i], direct[i] ? user_ptr(i, c) : s.host + off_host[i], chunk_size(i, nb), hipMemcpyHostToDevice, s_in_);
+            if (e == hipSuccess) e = hipEventRecord(ev_in_[si], s_in_);
+            if (e == hipSuccess) e = hipStreamWaitEvent(ks, ev_in_[si], 0);
+            if (e != hipSuccess) { drain(); return api_fail_hip(e, "host call: H2D"); }
+        }
+        rc = launch(dev, nb, ks);
+        if (rc != GFDM_HIP_OK) { drain(); return rc; }
+        ++st.chunks;
+        if (ce_out) {
+            e = hipEventRecord(ev_k_[si], ks);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s_out_, ev_k_[si], 0);
+            for (int i = 0; i < nops && e == hipSuccess; ++i)
+                if (ce[i] && ops[i].write)
+                    e = hipMemcpyAsync(direct[i] ? user_ptr(i, c) : s.host + off_host[i], s.dcopy + off_dev[i], chunk_size(i, nb), hipMemcpyDeviceToHost, s_out_);
+            if (e != hipSuccess) { drain(); return api_fail_hip(e, "host call: D2H"); }
+        }
+        want[si] = ++ticket_next_;
+        e = post_ticket(done_stream(c), si, want[si]);
+        if (e != hipSuccess) { drain(); return api_fail_hip(e, "host call: ticket"); }
+    }
+    for (int64_t c = retired; c < nchunks; ++c) {
+        const int si = (int)(c % depth);
+        hipError_t e = wait_ticket(done_stream(c), si, want[si]);
+        if (e != hipSuccess) { drain(); return api_fail_hip(e, "host call"); }
+        add_copy_out(c);
+        run_job();
+    }
+    return GFDM_HIP_OK;
+}
+
+int HostPipe::ensure_second_stream()
+{
+    if (!s_b_ && hipStreamCreateWithFlags(&s_b_, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return api_fail(GFDM_HIP_EHIP, "hipStreamCreate"); }
+    return GFDM_HIP_OK;
+}
+
+}  // namespace gfdm

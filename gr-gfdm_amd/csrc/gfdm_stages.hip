@@ -14,6 +14,7 @@
 #include "../../include/gfdm_hip.h"
 #include "gfdm_plan.h"
 #include "gfdm_dft.h"
+#include "gfdm_hostpipe.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -45,12 +46,11 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-// device, private stream and staging buffers of the *_host entry points
+// device, private stream and the host-buffer path (gfdm_hostpipe.h) of the *_host entry points
 struct StageCtx {
     int device = 0;
     hipStream_t stream = nullptr;
-    cf* stage[2] = { nullptr, nullptr };
-    size_t stage_elems[2] = { 0, 0 };
+    gfdm::HostPipe pipe;
     void* d_tables = nullptr;
 
     int open(int dev)
@@ -71,42 +71,26 @@ struct StageCtx {
         if (bytes) STAGE_TRY(hipMemcpy(d_tables, host, bytes, hipMemcpyHostToDevice));
         return GFDM_HIP_OK;
     }
-    int ensure(int which, size_t elems)
-    {
-        if (stage_elems[which] >= elems) return GFDM_HIP_OK;
-        if (stage[which]) (void)hipFree(stage[which]);
-        stage[which] = nullptr;
-        stage_elems[which] = 0;
-        if (hipMalloc(&stage[which], elems * sizeof(cf)) != hipSuccess) return api_fail(GFDM_HIP_ENOMEM, "device staging buffer allocation failed");
-        stage_elems[which] = elems;
-        return GFDM_HIP_OK;
-    }
     ~StageCtx()
     {
         DeviceGuard guard(device);
-        for (auto& s : stage) if (s) (void)hipFree(s);
+        pipe.release();
         if (d_tables) (void)hipFree(d_tables);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
 
-// stage in, launch, copy back: the host-pointer form of a device entry point
+// the host-pointer form of a device entry point: out_pb / in_pb complex samples per block, enqueue(out, in, nb, stream) -> status
 template <class Enqueue>
-int run_host(StageCtx& c, float* out, size_t out_elems, const float* in, size_t in_elems, int64_t nblocks, Enqueue&& enqueue)
+int run_host(StageCtx& c, float* out, size_t out_pb, const float* in, size_t in_pb, int64_t nblocks, Enqueue&& enqueue)
 {
     if (nblocks < 0 || !out || !in) return api_fail(GFDM_HIP_EINVAL, "NULL buffer or negative block count");
     if (nblocks == 0) return GFDM_HIP_OK;
     DeviceGuard guard(c.device);
     if (!guard.ok) return api_fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
-    int rc = c.ensure(0, in_elems > 0 ? in_elems : 1);
-    if (rc == GFDM_HIP_OK) rc = c.ensure(1, out_elems > 0 ? out_elems : 1);
-    if (rc != GFDM_HIP_OK) return rc;
-    if (in_elems) STAGE_TRY(hipMemcpyAsync(c.stage[0], in, in_elems * sizeof(cf), hipMemcpyHostToDevice, c.stream));
-    rc = enqueue(c.stage[1], c.stage[0], c.stream);
-    if (rc != GFDM_HIP_OK) return rc;
-    if (out_elems) STAGE_TRY(hipMemcpyAsync(out, c.stage[1], out_elems * sizeof(cf), hipMemcpyDeviceToHost, c.stream));
-    STAGE_TRY(hipStreamSynchronize(c.stream));
-    return GFDM_HIP_OK;
+    const gfdm::HostOperand ops[2] = { { out, out_pb * sizeof(cf), out_pb * sizeof(cf), true }, { const_cast<float*>(in), in_pb * sizeof(cf), in_pb * sizeof(cf), false } };
+    auto fn = [&](void* const* d, int64_t nb, hipStream_t s) { return enqueue(static_cast<cf*>(d[0]), static_cast<const cf*>(d[1]), nb, s); };
+    return c.pipe.run(c.stream, ops, 2, nblocks, fn);
 }
 
 constexpr int kThreads = 256;
@@ -365,9 +349,8 @@ int gfdm_hip_resource_mapper_map_host(gfdm_hip_resource_mapper* m, float* out, c
     if (!m) return api_fail(GFDM_HIP_EINVAL, "NULL handle");
     int rc = mapper_check(m, ninput_size, "input");
     if (rc != GFDM_HIP_OK) return rc;
-    const size_t nb = nblocks > 0 ? (size_t)nblocks : 0;
-    return run_host(m->ctx, out, nb * (size_t)(m->K * m->M), in, nb * (size_t)ninput_size, nblocks, [&](cf* o, const cf* i, hipStream_t s) {
-        return gfdm_hip_resource_mapper_map_device(m, o, i, ninput_size, nblocks, (void*)s);
+    return run_host(m->ctx, out, (size_t)(m->K * m->M), in, (size_t)ninput_size, nblocks, [&](cf* o, const cf* i, int64_t nb, hipStream_t s) {
+        return gfdm_hip_resource_mapper_map_device(m, o, i, ninput_size, nb, (void*)s);
     });
 }
 
@@ -376,9 +359,8 @@ int gfdm_hip_resource_mapper_demap_host(gfdm_hip_resource_mapper* m, float* out,
     if (!m) return api_fail(GFDM_HIP_EINVAL, "NULL handle");
     int rc = mapper_check(m, noutput_size, "output");
     if (rc != GFDM_HIP_OK) return rc;
-    const size_t nb = nblocks > 0 ? (size_t)nblocks : 0;
-    return run_host(m->ctx, out, nb * (size_t)noutput_size, in, nb * (size_t)(m->K * m->M), nblocks, [&](cf* o, const cf* i, hipStream_t s) {
-        return gfdm_hip_resource_mapper_demap_device(m, o, i, noutput_size, nblocks, (void*)s);
+    return run_host(m->ctx, out, (size_t)noutput_size, in, (size_t)(m->K * m->M), nblocks, [&](cf* o, const cf* i, int64_t nb, hipStream_t s) {
+        return gfdm_hip_resource_mapper_demap_device(m, o, i, noutput_size, nb, (void*)s);
     });
 }
 
@@ -458,18 +440,16 @@ int gfdm_hip_cyclic_prefixer_remove_device(gfdm_hip_cyclic_prefixer* c, void* ou
 int gfdm_hip_cyclic_prefixer_add_host(gfdm_hip_cyclic_prefixer* c, float* out, const float* in, int cyclic_shift, int64_t nblocks)
 {
     if (!c) return api_fail(GFDM_HIP_EINVAL, "NULL handle");
-    const size_t nb = nblocks > 0 ? (size_t)nblocks : 0;
-    return run_host(c->ctx, out, nb * (size_t)(c->N + c->cp + c->cs), in, nb * (size_t)c->N, nblocks, [&](cf* o, const cf* i, hipStream_t s) {
-        return gfdm_hip_cyclic_prefixer_add_device(c, o, i, cyclic_shift, nblocks, (void*)s);
+    return run_host(c->ctx, out, (size_t)(c->N + c->cp + c->cs), in, (size_t)c->N, nblocks, [&](cf* o, const cf* i, int64_t nb, hipStream_t s) {
+        return gfdm_hip_cyclic_prefixer_add_device(c, o, i, cyclic_shift, nb, (void*)s);
     });
 }
 
 int gfdm_hip_cyclic_prefixer_remove_host(gfdm_hip_cyclic_prefixer* c, float* out, const float* in, int64_t nblocks)
 {
     if (!c) return api_fail(GFDM_HIP_EINVAL, "NULL handle");
-    const size_t nb = nblocks > 0 ? (size_t)nblocks : 0;
-    return run_host(c->ctx, out, nb * (size_t)c->N, in, nb * (size_t)(c->N + c->cp + c->cs), nblocks, [&](cf* o, const cf* i, hipStream_t s) {
-        return gfdm_hip_cyclic_prefixer_remove_device(c, o, i, nblocks, (void*)s);
+    return run_host(c->ctx, out, (size_t)c->N, in, (size_t)(c->N + c->cp + c->cs), nblocks, [&](cf* o, const cf* i, int64_t nb, hipStream_t s) {
+        return gfdm_hip_cyclic_prefixer_remove_device(c, o, i, nb, (void*)s);
     });
 }
 

@@ -56,6 +56,12 @@ def lib():
         "gfdm_hip_set_dft_matrix_cores": (i32, [i32]),
         "gfdm_hip_jit_build_for_testing": (i32, [i32, i32, i32, i32]),
         "gfdm_hip_version": (cp, []),
+        "gfdm_hip_build_id": (cp, []),
+        "gfdm_hip_register_host": (i32, [vp, ctypes.c_size_t]),
+        "gfdm_hip_unregister_host": (i32, [vp]),
+        "gfdm_hip_set_host_pipeline": (i32, [i32, i64, i32, i32, i32]),
+        "gfdm_hip_get_host_pipeline": (i32, [vp, vp, vp, vp, vp]),
+        "gfdm_hip_host_call_stats": (i32, [vp, vp, vp, vp, vp, vp]),
         "gfdm_hip_modulator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
         "gfdm_hip_modulator_destroy": (i32, [vp]),
         "gfdm_hip_modulator_block_size": (i32, [vp]),
@@ -258,6 +264,69 @@ def quiesce():
     lib().gfdm_hip_quiesce()
 
 
+def build_id():
+    """gfdm_hip_build_id: hash of the sources and flags the loaded library was built from."""
+    return lib().gfdm_hip_build_id().decode()
+
+
+HOST_ZERO_COPY, HOST_COPY_ENGINES = 0, 1
+
+
+def set_host_pipeline(mode=-1, chunk_bytes=-1, depth=-1, copy_threads=-1, kernel_streams=-1):
+    """gfdm_hip_set_host_pipeline: tuning of the *_host calls' bounce through pinned staging (negative / omitted = unchanged).  Returns the
+    previous (mode, chunk_bytes, depth, copy_threads, kernel_streams)."""
+    prev = get_host_pipeline()
+    _check(lib().gfdm_hip_set_host_pipeline(int(mode), int(chunk_bytes), int(depth), int(copy_threads), int(kernel_streams)))
+    return prev
+
+
+def get_host_pipeline():
+    m, c, d, t, k = ctypes.c_int(0), ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib().gfdm_hip_get_host_pipeline(ctypes.byref(m), ctypes.byref(c), ctypes.byref(d), ctypes.byref(t), ctypes.byref(k)))
+    return m.value, c.value, d.value, t.value, k.value
+
+
+def host_call_stats():
+    """What the calling thread's last *_host call did: dict(chunks, chunk_blocks, staged_bytes, direct_mask, mode, copy_threads)."""
+    ch, cb, sb = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    dm, md, ct = ctypes.c_uint(0), ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib().gfdm_hip_host_call_stats(ctypes.byref(ch), ctypes.byref(cb), ctypes.byref(sb), ctypes.byref(dm), ctypes.byref(md), ctypes.byref(ct)))
+    return dict(chunks=ch.value, chunk_blocks=cb.value, staged_bytes=sb.value, direct_mask=dm.value, mode=md.value, copy_threads=ct.value)
+
+
+class registered_host:
+    """gfdm_hip_register_host as a context manager: `with registered_host(a, b): dem.demodulate(a, out=b)` -- the numpy arrays are pinned and
+    mapped for the GPUs, *_host calls on them run in place (no bounce).  A long-lived buffer is registered once with register_host()."""
+
+    def __init__(self, *arrays):
+        self._arrays = arrays
+
+    def __enter__(self):
+        done = []
+        try:
+            for a in self._arrays:
+                register_host(a)
+                done.append(a)
+        except Exception:
+            for a in done:
+                unregister_host(a)
+            raise
+        return self
+
+    def __exit__(self, *exc):
+        for a in self._arrays:
+            unregister_host(a)
+        return False
+
+
+def register_host(array):
+    _check(lib().gfdm_hip_register_host(array.ctypes.data, array.nbytes))
+
+
+def unregister_host(array):
+    _check(lib().gfdm_hip_unregister_host(array.ctypes.data))
+
+
 def set_dft_matrix_cores(mode):
     """gfdm_hip_set_dft_matrix_cores: where the generic kernel family of handles created afterwards runs its timeslot transforms on the
     matrix cores (f32 MFMA; from 32 timeslots on) -- 0 / False never, 1 / True (default) where that is the faster form, 2 wherever the form
@@ -373,7 +442,9 @@ class _Kernel:
             raise RuntimeError("%s vector size(%d) MUST be a multiple of block_size(%d)!" % (what, size, n))
         return size // n
 
-    def _host(self, fn, x, extra=(), extra_ok_none=False):
+    def _host(self, fn, x, extra=(), extra_ok_none=False, out=None):
+        """numpy path: the *_host entry point on the arrays' memory.  `out`: an existing complex64 array to write into (e.g. one registered with
+        register_host, so that the call runs in place on it)."""
         x = _c64(x)
         nb = self._nblocks(x.size)
         ptrs = []
@@ -389,7 +460,10 @@ class _Kernel:
                     raise RuntimeError("Channel vector size(%d) MUST be equal to input size(%d)!" % (e.size, x.size))
                 keep.append(e)
                 ptrs.append(e.ctypes.data)
-        out = np.empty(x.shape, np.complex64)
+        if out is None:
+            out = np.empty(x.shape, np.complex64)
+        elif not (isinstance(out, np.ndarray) and out.dtype == np.complex64 and out.flags.c_contiguous and out.size == x.size):
+            raise TypeError("out must be a C-contiguous complex64 numpy array of the input's size")
         _check(fn(self._h, out.ctypes.data, x.ctypes.data, *ptrs, nb))
         return out
 
@@ -437,7 +511,7 @@ class Modulator(_Kernel):
             import torch
             out = torch.empty_like(x) if out is None else out
             return self._device(lib().gfdm_hip_modulator_work_device, out, x, stream=stream)
-        return self._host(lib().gfdm_hip_modulator_work_host, x)
+        return self._host(lib().gfdm_hip_modulator_work_host, x, out=out)
 
 
 class Demodulator(_Kernel):
@@ -489,7 +563,7 @@ class Demodulator(_Kernel):
             import torch
             out = torch.empty_like(x) if out is None else out
             return self._device(getattr(L, name + "_device"), out, x, extra, stream)
-        return self._host(getattr(L, name + "_host"), x, extra, extra_ok_none)
+        return self._host(getattr(L, name + "_host"), x, extra, extra_ok_none, out=out)
 
     def demodulate(self, x, out=None, stream=None):
         return self._call("gfdm_hip_receiver_demodulate", x, (None,), out, stream, True)
@@ -560,7 +634,7 @@ class AdvancedReceiver(_Kernel):
             import torch
             out = torch.empty_like(x) if out is None else out
             return self._device(L.gfdm_hip_advanced_receiver_work_device, out, x, (f_eq,), stream)
-        return self._host(L.gfdm_hip_advanced_receiver_work_host, x, (f_eq,), True)
+        return self._host(L.gfdm_hip_advanced_receiver_work_host, x, (f_eq,), True, out=out)
 
     def demodulate(self, x, out=None, stream=None):
         """generic_work: IC receiver without equaliser."""

@@ -12,8 +12,8 @@
  *     samples; batched calls take `nblocks` blocks back to back (block stride = block_size),
  *     exactly the stream layout the GNU Radio wrappers feed one block at a time
  *     (lib/simple_receiver_cc_impl.cc:70-74, lib/advanced_receiver_sb_cc_impl.cc:98-113).
- *   - `*_host` calls take host pointers, stage H2D, launch, stage D2H and return when the
- *     result is in `out` (the reference's synchronous generic_work contract).
+ *   - `*_host` calls take host pointers and return when the result is in `out` (the reference's
+ *     synchronous generic_work contract); see "the host-buffer batch path" below for how the bytes move.
  *   - `*_device` calls take device pointers on the handle's device and only ENQUEUE work on
  *     `stream` (a hipStream_t passed as void*, NULL = default stream).  No synchronisation,
  *     no allocation: they are hipGraph-capturable.  Buffers must not alias.
@@ -27,6 +27,7 @@
 #ifndef GFDM_HIP_H
 #define GFDM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -111,6 +112,40 @@ int gfdm_hip_set_dft_matrix_cores(int mode);
  * needs no GPU, so the CPU-side tests can check that the embedded kernel sources build. */
 int gfdm_hip_jit_build_for_testing(int timeslots, int subcarriers, int overlap, int part);
 const char* gfdm_hip_version(void);
+/* 16 hex digits: hash of the kernel / C-ABI sources and compiler flags this library was built from.  The rocprofv3 summaries under
+ * profiles/ name the build they were measured with; bench.py only quotes counters whose build id equals the loaded library's. */
+const char* gfdm_hip_build_id(void);
+
+/* ---- the host-buffer batch path (*_host entry points) -------------------------------------------------------------------------
+ * The reference's callers hand HOST pointers and advance them block by block (lib/simple_receiver_cc_impl.cc:61-77,
+ * lib/advanced_receiver_sb_cc_impl.cc:86-123 -- in, f_eq and out --, lib/transmitter_cc_impl.cc:165-177); a *_host call takes the
+ * whole run of a scheduler call.  How its bytes cross the PCIe link:
+ *   - buffers the GPU can address -- registered with gfdm_hip_register_host, allocated with hipHostMalloc, or device memory -- are
+ *     used IN PLACE: the kernels run on the caller's memory, bound by the link (~57 GB/s each way on the MI355X boxes);
+ *   - ordinary pageable buffers are bounced through pinned staging sets in chunks: the kernel of chunk c works across the link
+ *     while the calling thread and a small pool of copy threads move chunk c + 1 in and chunk c - 1 out.  A call that fits one
+ *     chunk (<= 1 MiB, e.g. the one block per call of an unchanged GNU Radio wrapper) is copy in, one launch, completion ticket, copy out.
+ *   Measured (MI355X box, K=64 M=9, profiles/r04/): pageable 6.7 M blocks/s matched filter, 5.4 M ZF + 2 IC at 65 536 blocks per call;
+ *   registered 9.6 M / 6.0 M (88 / 82 GB/s over the link, both directions together); one block per call 13 us either way.
+ * Results do not depend on the route (same kernels, same blocks).  The call returns when `out` is complete.
+ *
+ * gfdm_hip_register_host: pin a long-lived buffer (a GNU Radio circular buffer, an application's frame store) and map it for every GPU,
+ * ~16 us per MiB once; later *_host calls on any part of it skip the bounce.  Unregister before the memory is freed. */
+int gfdm_hip_register_host(void* ptr, size_t bytes);
+int gfdm_hip_unregister_host(void* ptr);
+/* Process-wide tuning of the bounce (negative = leave unchanged).  mode = how the bytes cross the link: 0 (default) under the kernels' own
+ * accesses to the pinned staging memory, 1 copy engines (H2D / kernel / D2H on three streams, device staging), 2 inputs under the kernel's
+ * reads and outputs by copy engine, 3 the reverse -- 1 .. 3 are kept for A/B measurements (profiles/r04/host_path_sweep.txt: mode 0 wins
+ * or ties everywhere but the largest matched-filter calls); chunk_bytes = staged bytes per chunk over all operands, 0 = automatic (one chunk
+ * up to 1 MiB, else total / 8 within 512 KiB .. 16 MiB); depth = staging sets (1 .. 4, default 3); copy_threads = pool threads that help the
+ * calling thread with the bounce copies of chunks >= 512 KiB (0 .. 16, default 3); kernel_streams = 2 (default): the chunks alternate
+ * between two streams (a kernel reads its blocks, then writes them, i.e. uses one direction of the link at a time; with two streams the
+ * reads of one chunk can run under the writes of another), 1 = a single stream. */
+int gfdm_hip_set_host_pipeline(int mode, int64_t chunk_bytes, int depth, int copy_threads, int kernel_streams);
+int gfdm_hip_get_host_pipeline(int* mode, int64_t* chunk_bytes, int* depth, int* copy_threads, int* kernel_streams);
+/* What the last *_host call of the calling thread did (any pointer may be NULL): kernel launches, blocks per chunk, bytes bounced,
+ * bit i of direct_mask = operand i was used in place (operands in signature order: outputs first, then inputs), route, pool threads used. */
+int gfdm_hip_host_call_stats(int64_t* chunks, int64_t* chunk_blocks, int64_t* staged_bytes, unsigned* direct_mask, int* mode, int* copy_threads);
 
 /* ---- modulator_kernel_cc (include/gfdm/modulator_kernel_cc.h:41-51) -------------------- */
 

@@ -1,0 +1,230 @@
+"""The host-buffer batch path (gr-gfdm_amd/csrc/gfdm_hostpipe.{h,hip}): what the reference's GNU Radio wrappers call -- HOST pointers, a run
+of blocks per scheduler call, three pointers advanced per block
+    lib/simple_modulator_cc_impl.cc:62-80, lib/simple_receiver_cc_impl.cc:61-77, lib/advanced_receiver_sb_cc_impl.cc:86-123,
+    lib/transmitter_cc_impl.cc:165-177.
+The route a call takes (in place on registered memory, one chunk, a chunked bounce through pinned staging sets, kernels across the link or copy
+engines, with or without the copy threads) must not change a single bit of the result: every case is compared for EQUALITY with the
+device-pointer path on the same blocks, for ragged block counts around the chunk size (0, 1, chunk - 1, chunk, chunk + 1, many chunks + 1) and
+at 65 537 blocks with the automatic chunk plan."""
+import numpy as np
+import pytest
+
+import gfdm_ref as R
+from conftest import have_gpu, load_est_golden
+from gfdm_amd.filters import get_frequency_domain_filter
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu():
+    if not have_gpu():
+        pytest.fail("no MI355X visible: the HIP path cannot run (there is no CPU fallback to test instead)")
+
+
+@pytest.fixture()
+def pipeline():
+    """restores the process-wide settings of the host path after a test that changes them"""
+    import gfdm_amd
+    prev = gfdm_amd.get_host_pipeline()
+    yield gfdm_amd
+    gfdm_amd.set_host_pipeline(*prev)
+
+
+def qpsk(rng, shape):
+    return (((1 - 2 * rng.integers(0, 2, shape)) + 1j * (1 - 2 * rng.integers(0, 2, shape))) / np.sqrt(2)).astype(np.complex64)
+
+
+def device_reference(call, *arrays):
+    """the same entry point on device-resident tensors (torch holds the memory), back on the host"""
+    import torch
+    dev = [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrays]
+    out = call(*dev)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+CHUNK = 8      # blocks per chunk in the ragged tests
+
+
+@pytest.mark.parametrize("mode,threads,streams", [(0, 0, 1), (0, 2, 2), (0, 0, 2), (1, 0, 1), (1, 2, 2), (2, 2, 1), (2, 0, 2), (3, 1, 1)])
+def test_chunked_bounce_equals_the_device_path_for_ragged_block_counts(pipeline, mode, threads, streams):
+    g = pipeline
+    g.set_host_pipeline(kernel_streams=streams)
+    M, K, L = 9, 64, 2
+    N = M * K
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    mod, dem = g.Modulator(M, K, L, taps), g.Demodulator(M, K, L, taps)
+    adv = g.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+    rng = np.random.default_rng(4)
+    nmax = 5 * CHUNK + 1
+    sym = qpsk(rng, (nmax, N))
+    frames = device_reference(lambda s: mod.modulate(s), sym)
+    feq = (1.0 + 0.3 * (rng.standard_normal((nmax, N)) + 1j * rng.standard_normal((nmax, N)))).astype(np.complex64)
+    ref_mod, ref_mf = frames, device_reference(lambda x: dem.demodulate(x), frames)
+    ref_zf = device_reference(lambda x, e: dem.demodulate_equalize(x, e), frames, feq)
+    ref_ic = device_reference(lambda x, e: adv.demodulate_equalize(x, e), frames, feq)
+    # chunk size in bytes of ALL staged operands: MF / modulate stage 2 x 8 N bytes per block, ZF 3 x 8 N
+    for nb in (0, 1, CHUNK - 1, CHUNK, CHUNK + 1, 3 * CHUNK, nmax):
+        g.set_host_pipeline(mode, CHUNK * 16 * N, 3, threads)
+        out = mod.modulate(sym[:nb])
+        assert out.shape == (nb, N) and np.array_equal(out, ref_mod[:nb])
+        st = g.host_call_stats()
+        if nb:
+            assert st["chunks"] == -(-nb // CHUNK) and st["chunk_blocks"] == min(CHUNK, nb) and st["direct_mask"] == 0 and st["mode"] == mode
+            assert st["staged_bytes"] == 16 * N * nb
+        assert np.array_equal(dem.demodulate(frames[:nb]), ref_mf[:nb])
+        g.set_host_pipeline(mode, CHUNK * 24 * N, 2, threads)
+        assert np.array_equal(dem.demodulate_equalize(frames[:nb], feq[:nb]), ref_zf[:nb])
+        assert np.array_equal(adv.demodulate_equalize(frames[:nb], feq[:nb]), ref_ic[:nb])
+        if nb:
+            assert g.host_call_stats()["chunks"] == -(-nb // CHUNK)
+    # one block per chunk, a single staging set: the degenerate pipeline
+    g.set_host_pipeline(mode, 1, 1, threads)
+    assert np.array_equal(adv.demodulate_equalize(frames[:5], feq[:5]), ref_ic[:5])
+    assert g.host_call_stats()["chunks"] == 5
+
+
+def test_registered_buffers_are_used_in_place(pipeline):
+    g = pipeline
+    M, K, L = 9, 64, 2
+    N = M * K
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    mod = g.Modulator(M, K, L, taps)
+    adv = g.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+    rng = np.random.default_rng(5)
+    nb = 300
+    sym = qpsk(rng, (nb, N))
+    frames = mod.modulate(sym)
+    feq = (1.0 + 0.3 * (rng.standard_normal((nb, N)) + 1j * rng.standard_normal((nb, N)))).astype(np.complex64)
+    ref = adv.demodulate_equalize(frames, feq)                        # bounced (pageable numpy memory)
+    assert g.host_call_stats()["direct_mask"] == 0 and g.host_call_stats()["chunks"] >= 2
+    out = np.empty_like(ref)
+    with g.registered_host(out, frames, feq):
+        res = adv.demodulate_equalize(frames, feq, out=out)
+        st = g.host_call_stats()
+        assert res is out and st["direct_mask"] == 0b111 and st["staged_bytes"] == 0
+        assert st["chunks"] == 1                      # kernels on the caller's memory: one launch
+        assert np.array_equal(out, ref)
+        for mode in (1, 2, 3):                        # copy engines between the caller's memory and device staging, chunk by chunk
+            g.set_host_pipeline(mode, 7 * 24 * N, 3, 0)
+            out[:] = 0
+            adv.demodulate_equalize(frames, feq, out=out)
+            st = g.host_call_stats()
+            assert st["chunks"] == -(-nb // 7) and st["direct_mask"] == 0b111 and st["staged_bytes"] == 0 and np.array_equal(out, ref)
+        g.set_host_pipeline(0, 0, 3, 2)
+        # any part of a registered buffer: interior pointers, ragged counts
+        out[:] = 0
+        adv.demodulate_equalize(frames[7:130], feq[7:130], out=out[7:130])
+        assert g.host_call_stats()["direct_mask"] == 0b111
+        assert np.array_equal(out[7:130], ref[7:130]) and not out[:7].any() and not out[130:].any()
+        # in place (out is in): the reference's generic_work copies its input first, so callers may rely on it -- the output is bounced
+        buf = frames.copy()
+        g.register_host(buf)
+        try:
+            mf = g.Demodulator(M, K, L, taps)
+            want = mf.demodulate(frames)
+            mf.demodulate(buf, out=buf)
+            assert g.host_call_stats()["direct_mask"] == 0b10          # operand 0 (out) staged, operand 1 (in) in place
+            assert np.array_equal(buf, want)
+        finally:
+            g.unregister_host(buf)
+    # mixed: only the input registered
+    with g.registered_host(frames):
+        g.set_host_pipeline(0, CHUNK * 16 * N, 3, 0)
+        assert np.array_equal(adv.demodulate_equalize(frames, feq), ref)
+        st = g.host_call_stats()
+        assert st["direct_mask"] == 0b010 and st["chunks"] == -(-nb // CHUNK) and st["staged_bytes"] == 16 * N * nb
+    # after unregistering the memory is ordinary again
+    adv.demodulate_equalize(frames, feq)
+    assert g.host_call_stats()["direct_mask"] == 0
+    with pytest.raises(Exception):
+        g.unregister_host(frames)
+
+
+def test_65537_blocks_with_the_automatic_chunk_plan(pipeline):
+    g = pipeline
+    M, K, L = 9, 64, 2
+    N = M * K
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    mod, dem = g.Modulator(M, K, L, taps), g.Demodulator(M, K, L, taps)
+    nb = 65537
+    rng = np.random.default_rng(6)
+    sym = qpsk(rng, (nb, N))
+    frames = mod.modulate(sym)
+    st = g.host_call_stats()
+    assert st["chunks"] > 8 and st["direct_mask"] == 0 and st["copy_threads"] >= 1
+    assert np.array_equal(frames, device_reference(lambda s: mod.modulate(s), sym))
+    out = dem.demodulate(frames)
+    assert np.array_equal(out, device_reference(lambda x: dem.demodulate(x), frames))
+    # size-independent property at the full size: the matched-filter receiver returns the symbols up to the filter's self-interference
+    assert np.max(np.abs(out[-1] - sym[-1])) < 0.6 and np.array_equal(np.sign(out.real[::4097]), np.sign(sym.real[::4097]))
+    reg = np.empty_like(out)
+    with g.registered_host(frames, reg):
+        dem.demodulate(frames, out=reg)
+        assert g.host_call_stats()["chunks"] == 1 and g.host_call_stats()["staged_bytes"] == 0
+    assert np.array_equal(reg, out)
+
+
+def test_other_entry_points_through_the_chunked_bounce(pipeline):
+    """frames + demapper, the self-estimating receiver with preambles at a stride inside a burst buffer, the stand-alone estimator with its
+    float outputs (estimate_snr), the composite transmitter with two output ports, mapper and prefixer: chunked == one chunk"""
+    g = pipeline
+    e = load_est_golden("est_cfg2_m9_k64_a52")
+    M, K, A = e["M"], e["K"], e["A"]
+    L, N = 2, M * K
+    rng = np.random.default_rng(7)
+    smap = np.concatenate((np.arange(1, A // 2 + 1), np.arange(K - A // 2, K)))
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    est = g.ChannelEstimator(M, K, A, True, 1, e["preamble"])
+    adv = g.AdvancedReceiver(M, K, L, taps, smap, 2, R.qpsk_points())
+    cp, nb = 16, 37
+    adv.configure_frames(cp + N + 8, cp, smap, True)
+    adv.set_channel_estimator(est)
+    burst_len = 2 * K + cp + N + 8
+    bursts = (rng.standard_normal((nb, burst_len)) + 1j * rng.standard_normal((nb, burst_len))).astype(np.complex64)
+    mapper = g.ResourceMapper(M, K, A, smap, True)
+    prefixer = g.CyclicPrefixer(N, cp, 8, 4, np.ones(2 * 4, np.complex64), 0)
+    tx = g.Transmitter(M, K, A, cp, 8, 4, smap, True, L, taps, np.ones(2 * 4, np.complex64), [0, 3],
+                       (rng.standard_normal((2, 2 * K)) + 1j * rng.standard_normal((2, 2 * K))).astype(np.complex64))
+    data = qpsk(rng, (nb, A * M))
+    blocks = qpsk(rng, (nb, N))
+
+    def everything():
+        frames = np.ascontiguousarray(bursts[:, 2 * K:])
+        res = [adv.demodulate_frames(frames, None)]
+        res.append(adv.demodulate_estimated(frames, np.ascontiguousarray(bursts[:, :2 * K])))                  # packed preambles
+        res.append(adv.demodulate_estimated(frames, bursts.reshape(-1), preamble_stride=burst_len))           # preamble b at b * burst_len
+        assert np.array_equal(res[-1], res[-2])
+        res.append(est.estimate_frame(np.ascontiguousarray(bursts[:, :2 * K])))
+        res.extend(est.estimate_snr(np.ascontiguousarray(bursts[:, :2 * K])))
+        res.extend(tx.generic_work(data))
+        res.append(mapper.map_to_resources(data))
+        res.append(mapper.demap_from_resources(blocks))
+        res.append(prefixer.add_cyclic_prefix(blocks))
+        return [np.asarray(r) for r in res]
+
+    g.set_host_pipeline(0, 1 << 30, 3, 0)
+    whole = everything()
+    for mode, chunk, depth, threads in ((0, 5 * 8 * N, 3, 2), (1, 3 * 8 * N, 2, 0), (0, 1, 4, 0), (2, 4 * 8 * N, 3, 1), (3, 9 * 8 * N, 2, 0)):
+        g.set_host_pipeline(mode, chunk, depth, threads)
+        parts = everything()
+        assert len(parts) == len(whole)
+        for a, b in zip(parts, whole):
+            assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def test_copy_threads_are_stopped_by_quiesce_and_come_back(pipeline):
+    g = pipeline
+    M, K, L = 9, 64, 2
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    mod = g.Modulator(M, K, L, taps)
+    sym = qpsk(np.random.default_rng(8), (2048, M * K))
+    g.set_host_pipeline(0, 0, 3, 3)
+    a = mod.modulate(sym)
+    assert g.host_call_stats()["copy_threads"] >= 1
+    g.quiesce()
+    b = mod.modulate(sym)
+    assert g.host_call_stats()["copy_threads"] >= 1 and np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        g.set_host_pipeline(5, -1, -1, -1)
