@@ -22,10 +22,13 @@ processed / that time.
 
 Beside the headline the JSON line carries
   roofline        achieved HBM GB/s of the step's dominant (slowest) kernel = algorithmic bytes per launch (16 B/symbol,
-                  24 B/symbol with the per-block equaliser vector) / its mean duration, measured with HIP
-                  events on the launch stream around a back-to-back run of the timed steps' launches; `traffic` = HBM bytes per
-                  launch from the committed rocprofv3 PMC summary of the newest profiles/rNN/ (null when it has no row for this
-                  kernel and batch); `copy_ceiling_GBps` = a plain device copy of the same byte count timed the same way
+                  24 B/symbol with the per-block equaliser vector) / its duration, measured with HIP events on
+                  the launch stream: `kernel_ms` (and `achieved`, `frac`) = MEDIAN of event pairs around SINGLE launches (the form
+                  that agrees with rocprofv3's kernel duration); `kernel_ms_pipelined` = one event pair around the back-to-back run
+                  of the timed steps' launches (consecutive launches overlap head and tail: a loop property, not a kernel property);
+                  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary of the newest profiles/rNN/ -- only when
+                  that summary was measured with THIS build of the library (gfdm_hip_build_id), else null + `traffic_note`;
+                  `copy_ceiling_GBps` = a plain device copy of the same byte count, single launches timed the same way
   roofline_kernels  the same figures for every kernel of the step (cfg2: modulate and demodulate)
   sustained       the headline loop again for >= 2 s (the default 200 steps are a ~4 ms burst; boxes boost for short bursts)
   single_block_host_us   one generic_work(out, in) with HOST pointers through the pybind11 drop-in class (host copy into the pinned
@@ -34,6 +37,11 @@ Beside the headline the JSON line carries
                   thread (oracle/gfdm_oracle_bench.c), all CPUs this process may run on; single thread beside it
   paths / large_batch   (N = 1, cfg2 / cfg3 only) every receiver variant and the modulator alone on the stream, and the same
                   kernels at 65 536 blocks per launch
+  paths.host_batch_{modulate,demod_mf,zf_ic2}   the *_host entry points -- what gr-gfdm's GNU Radio wrappers call, HOST pointers --
+                  at 1 / 16 / 256 / 4096 / 65 536 blocks per call: blocks/s and bytes over the PCIe link per second, on pageable
+                  memory (bounced through the pinned staging sets) and on memory registered with gfdm_hip_register_host (used in
+                  place); `cpu_port` = the plain-C port of the reference algorithm on the same call, one thread (how a GNU Radio block
+                  runs it) and all threads this process may use
 """
 import argparse
 import ctypes
@@ -87,6 +95,10 @@ def parse(argv=None):
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained run of the headline loop (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the per-variant measurements")
+    ap.add_argument("--no-host-paths", action="store_true", help="skip the host-buffer (*_host entry points) measurements")
+    ap.add_argument("--host-sizes", default="1,16,256,4096,65536", help="blocks per call of the host-buffer measurements")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the barriers / stat all-reduces even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="wall time of each cpu_baseline leg (two or three legs)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N > 1 run (nccl = RCCL over xGMI; gloo lets several ranks share ONE GPU, "
@@ -186,7 +198,9 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
     ring slots with ONE HIP event pair on the launch stream around the back-to-back run of its `steps` launches, i.e. the
     launch-to-launch duration: the kernel itself plus the ~1.3 us dispatch gap between two dependent launches (an event pair
     around every single launch would add another ~2.6 us of event packets to each).
-    Returns (wall seconds of the timed region, [mean duration in ms of kernel j of a step] or None)."""
+    Each kernel is also timed launch by launch, every launch inside its own event pair (single_launch_ms): the median of those pairs
+    is the kernel's own duration.
+    Returns (wall seconds of the timed region, [pipelined mean in ms of kernel j of a step] or None, [single-launch median] or None)."""
     import torch
     import torch.distributed as dist
     nslots = len(step_fns)
@@ -195,8 +209,9 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
             f()
     gc.collect()
     gc.disable()                              # no collector pause (tens of ms with the tensor rings alive) inside the timed region
+    dist_on = dist.is_available() and dist.is_initialized()      # also a one-rank group (--force-dist / torchrun --nproc-per-node 1)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -206,12 +221,12 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0           # this rank's time for its K steps; the caller takes the MAX over ranks
     gc.enable()
-    if world > 1:
+    if dist_on:
         dist.barrier()                        # closing bracket: every rank has finished before anyone moves on
     torch.cuda.synchronize()
     if not time_kernels:
-        return wall, None
-    kern_ms = []
+        return wall, None, None
+    kern_ms, kern_single = [], []
     for j in range(len(step_fns[0])):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(min(warmup, 4)):
@@ -222,12 +237,31 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
         e1.record()
         torch.cuda.synchronize()
         kern_ms.append(e0.elapsed_time(e1) / steps)
-    return wall, kern_ms
+        kern_single.append(single_launch_ms(lambda i: step_fns[(warmup + i) % nslots][j](), min(steps, 200)))
+    return wall, kern_ms, kern_single
+
+
+def single_launch_ms(launch, n):
+    """median duration of `n` single launches, each inside its own HIP event pair, the pairs queued back to back on the stream (event,
+    launch(i), event, event, launch(i + 1), event ...): every pair spans one kernel from the end of its predecessor to its own end.  Of
+    the three ways to time a kernel with events this is the one that agrees with rocprofv3's kernel duration (same box, K=64 M=9, 4096
+    blocks, profiles/r04/event_timing_vs_rocprofv3.txt: rocprofv3 median 10.4 / 15.5 us MF / ZF + 2 IC, queued pairs 11.3 / 15.2 us; a
+    pair around a launch on an idle GPU reads 13.5 / 16.6 us, the back-to-back mean 9.7 / 13.4 us)."""
+    import torch
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    torch.cuda.synchronize()
+    for i in range(n):
+        evs[i][0].record()
+        launch(i)
+        evs[i][1].record()
+    torch.cuda.synchronize()
+    times = sorted(x.elapsed_time(y) for x, y in evs)
+    return times[len(times) // 2]
 
 
 def copy_ceiling(nbytes_moved, steps, ring_mib, dev):
     """GB/s of a plain device-to-device copy that moves the same number of bytes (half read, half written) as one launch of the
-    dominant kernel, timed like it (back to back over a ring, one event pair)."""
+    dominant kernel, timed like it (median of single launches over a ring)."""
     import torch
     n = max(1, nbytes_moved // 2)
     nslots = max(2, min(64, (ring_mib << 20) // (2 * n)))
@@ -235,26 +269,25 @@ def copy_ceiling(nbytes_moved, steps, ring_mib, dev):
     dst = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(nslots)]
     for i in range(4):
         dst[i % nslots].copy_(src[i % nslots])
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for i in range(steps):
-        dst[i % nslots].copy_(src[i % nslots])
-    e1.record()
-    torch.cuda.synchronize()
-    return 2.0 * n / (e0.elapsed_time(e1) / steps * 1e-3) / 1e9
+    ms = single_launch_ms(lambda i: dst[i % nslots].copy_(src[i % nslots]), min(steps, 200))
+    return 2.0 * n / (ms * 1e-3) / 1e9
 
 
-def pmc_traffic(kernel_template, batch):
+def pmc_traffic(kernel_template, batch, build_id=None):
     """HBM bytes per launch of `kernel_template` at `batch` blocks from the newest committed rocprofv3 PMC summary
     (profiles/rNN/pmc_hbm_traffic_summary.csv, rows `<run>_<batch>` per counter and kernel; FETCH_SIZE x 2 [gfx950 correction
     for this access width, calibrated on a copy kernel of the same shape -- MI355X_MICROARCH.md, HBM] + WRITE_SIZE, KiB).
-    Counters cannot be read from inside this process; None when the summary has no row for this kernel and batch."""
+    Counters cannot be read from inside this process.  A summary counts only if it was measured with the library that is loaded now:
+    its rows carry the build id (gfdm_hip_build_id) of the run.  Returns {"bytes", "source"} or {"bytes": None, "note": why}."""
+    note = "no committed PMC summary has a row for this kernel and batch"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_hbm_traffic_summary.csv")), reverse=True):
         fetch = write = None
         try:
             for row in csv.DictReader(open(path)):
                 if row["kernel"].replace(" ", "") != kernel_template.replace(" ", "") or not row["run"].endswith("_%d" % batch):
+                    continue
+                if build_id is not None and row.get("build_id") != build_id:
+                    note = "%s was measured with build %s, the loaded library is build %s" % (os.path.relpath(path, ROOT), row.get("build_id") or "(not recorded)", build_id)
                     continue
                 if row["counter"] == "FETCH_SIZE":
                     fetch = float(row["mean_KiB"])
@@ -264,7 +297,7 @@ def pmc_traffic(kernel_template, batch):
             continue
         if fetch is not None and write is not None:
             return {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT)}
-    return None
+    return {"bytes": None, "note": note}
 
 
 def allowed_cpus():
@@ -366,6 +399,88 @@ def cpu_baseline(cfg, taps, seconds):
             "reference_libs_present": {"fftw3f": ctypes.util.find_library("fftw3f") is not None, "volk": ctypes.util.find_library("volk") is not None}}
 
 
+def host_batch_paths(cfg, taps, sizes, seconds=0.3, cpu_seconds=1.0, with_cpu=True):
+    """The *_host entry points (HOST pointers: what gr-gfdm's GNU Radio wrappers call, lib/simple_receiver_cc_impl.cc:61-77,
+    lib/advanced_receiver_sb_cc_impl.cc:86-123, lib/simple_modulator_cc_impl.cc:62-80) at `sizes` blocks per call, on pageable numpy
+    memory and on the same arrays registered with gfdm_hip_register_host.  Per call size: blocks/s, algorithmic bytes over the PCIe link
+    per second (16 N per block, 24 N with the equaliser vector), microseconds per call, kernel launches of the call.  Beside them the
+    plain-C port of the reference algorithm on the same work: one thread (a GNU Radio block runs its kernel on one thread) and every
+    thread this process may use."""
+    import numpy as np
+    import gfdm_amd
+    K, M, L = cfg["K"], cfg["M"], cfg["L"]
+    N = K * M
+    qpsk = np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) / np.sqrt(2)
+    mod = gfdm_amd.Modulator(M, K, L, taps)
+    dem = gfdm_amd.Demodulator(M, K, L, np.conj(taps))
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, np.conj(taps), np.arange(K), 2, qpsk)
+    Lb = gfdm_amd.lib()
+    nmax = max(sizes)
+    bits = np.random.default_rng(0x6FD1).integers(0, 2, (nmax, N, 2), dtype=np.int8)
+    sym = np.empty((nmax, N), np.complex64)
+    sym.real = (2 * bits[:, :, 0] - 1) * np.float32(np.sqrt(0.5))
+    sym.imag = (2 * bits[:, :, 1] - 1) * np.float32(np.sqrt(0.5))
+    del bits
+    frames = mod.modulate(sym)
+    feq = np.ones((nmax, N), np.complex64)
+    out = np.empty((nmax, N), np.complex64)
+    vp = lambda x: None if x is None else ctypes.c_void_p(x.ctypes.data)
+    calls = {
+        "host_batch_modulate": (Lb.gfdm_hip_modulator_work_host, [mod._h, vp(out), vp(sym)], 16, ("mod", False, 0)),
+        "host_batch_demod_mf": (Lb.gfdm_hip_receiver_demodulate_host, [dem._h, vp(out), vp(frames), None], 16, ("demod", False, 0)),
+        "host_batch_zf_ic2": (Lb.gfdm_hip_advanced_receiver_work_host, [adv._h, vp(out), vp(frames), vp(feq)], 24, ("demod_ic", True, 2)),
+    }
+
+    def rate(fn, args, bps, nb):
+        full = args + [ctypes.c_int64(nb)]
+        for _ in range(2):
+            assert fn(*full) == 0
+        n, t0 = 0, time.perf_counter()
+        while True:
+            assert fn(*full) == 0
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > seconds and n >= 3:
+                break
+        st = gfdm_amd.host_call_stats()
+        return {"blocks_per_s": nb * n / dt, "link_GBps": bps * N * nb * n / dt / 1e9, "us_per_call": dt / n * 1e6, "launches_per_call": st["chunks"],
+                "in_place_operands": bin(st["direct_mask"]).count("1"), "copy_threads": st["copy_threads"]}
+
+    res = {}
+    for name, (fn, args, bps, _) in calls.items():
+        res[name] = {"algorithmic_link_bytes_per_block": bps * N, "pageable": {str(nb): rate(fn, args, bps, nb) for nb in sizes}}
+    with gfdm_amd.registered_host(sym, frames, feq, out):
+        for name, (fn, args, bps, _) in calls.items():
+            res[name]["registered"] = {str(nb): rate(fn, args, bps, nb) for nb in sizes}
+    mode, chunk, depth, threads, streams = gfdm_amd.get_host_pipeline()
+    settings = {"link_route": mode, "chunk_bytes": chunk or "auto", "staging_sets": depth, "copy_threads": threads, "kernel_streams": streams}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import c_oracle
+        try:
+            path = "/tmp/libgfdm_oracle_native_%d.so" % os.getpid()
+            if not os.path.exists(path):
+                c_oracle.build(cflags=["-O3", "-march=native"], out=path)
+            lib = c_oracle.load(path)
+        except Exception:
+            lib = c_oracle.load()
+        cpus = allowed_cpus()
+        quota = cgroup_cpu_quota()
+        T_all = len(cpus) if quota is None else max(1, min(len(cpus), int(quota + 0.999)))
+        chunk_c = max(1, 16384 // N * 4)
+        for name, (_, _, _, (cmode, use_eq, ic)) in calls.items():
+            n1, t1 = c_oracle.bench_threads(M, K, L, taps, cmode, 1, cpu_seconds, use_eq=use_eq, ic_iter=ic, cpus=cpus, chunk=chunk_c, lib=lib)
+            nT, tT = c_oracle.bench_threads(M, K, L, taps, cmode, T_all, cpu_seconds, use_eq=use_eq, ic_iter=ic, cpus=cpus, chunk=chunk_c, lib=lib)
+            big = str(max(sizes))
+            res[name]["cpu_port"] = {"kind": "port", "single_thread_blocks_per_s": n1 / t1, "threads": T_all, "blocks_per_s": nT / tT,
+                                     "gpu_pageable_over_cpu_single_thread": res[name]["pageable"][big]["blocks_per_s"] / (n1 / t1),
+                                     "gpu_pageable_over_cpu_all_threads": res[name]["pageable"][big]["blocks_per_s"] / (nT / tT),
+                                     "at_blocks_per_call": int(big)}
+    for name in res:
+        res[name]["settings"] = settings
+    return res
+
+
 def single_block_host(cfg, taps, reps=300):
     """One block through the literal drop-in path: gfdm_python.Demodulator.demodulate(ndarray) = receiver_kernel_cc::generic_work
     with host pointers (small calls: pinned GPU-mapped buffer, kernel, stream sync) -- what gr-gfdm's unchanged wrappers call once per block
@@ -409,7 +524,13 @@ def main():
         local = local % torch.cuda.device_count()                    # test mode: the ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # torch.distributed: always for N > 1; for one rank when asked (--force-dist) or when a torchrun environment is present (WORLD_SIZE=1),
+    # so that the RCCL group, the barriers and the two all-reduces of sharding.reduce_stats also run on a one-GPU box
+    use_dist = world > 1 or a.force_dist or "WORLD_SIZE" in os.environ
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL; only barriers / stat reductions
         else:
@@ -511,24 +632,24 @@ def main():
             sb_mod.prepare(L_.gfdm_hip_modulator_work_device, [frames[s]], [(sym[s],)], [B], [stream])()
         torch.cuda.synchronize()
     piped = step_fns_on(lambda s: side[s % S].cuda_stream, lag)
-    wall, _ = timed_loop(piped, a.steps, a.warmup, world, time_kernels=False)
+    wall = timed_loop(piped, a.steps, a.warmup, world, time_kernels=False)[0]
     total_blocks, _, wall_max = sharding.reduce_stats(B * a.steps, zeros3(), wall, dev)
     value = total_blocks / wall_max
     value_hot = None
     if lag:
         hot = step_fns_on(lambda s: side[s % S].cuda_stream, 0)
-        wall_h, _ = timed_loop(hot, a.steps, a.warmup, world, time_kernels=False)
+        wall_h = timed_loop(hot, a.steps, a.warmup, world, time_kernels=False)[0]
         hot_blocks, _, wall_h_max = sharding.reduce_stats(B * a.steps, zeros3(), wall_h, dev)
         value_hot = hot_blocks / wall_h_max
         del hot
     sustained = None
     if a.sustained_seconds > 0:
         nsus = max(a.steps, int(a.sustained_seconds / max(wall_max / a.steps, 1e-7)) + 1)
-        wsus, _ = timed_loop(piped, nsus, 0, world, time_kernels=False)
+        wsus = timed_loop(piped, nsus, 0, world, time_kernels=False)[0]
         sus_blocks, _, wsus_max = sharding.reduce_stats(B * nsus, zeros3(), wsus, dev)
         sustained = {"seconds": wsus_max, "steps": nsus, "value": sus_blocks / wsus_max, "ms_per_step": wsus_max / nsus * 1e3}
     single = step_fns_on(lambda s: stream, lag)
-    wall1, kern_ms = timed_loop(single, a.steps, a.warmup, world, time_kernels=True)
+    wall1, kern_ms, kern_single = timed_loop(single, a.steps, a.warmup, world, time_kernels=True)
     _, _, wall1_max = sharding.reduce_stats(0, zeros3(), wall1, dev)
     # output checksum of ring slot 0 (strong scaling: the union over the ranks is global blocks [0, total) whatever N is)
     for f in step_fns_on(lambda s: stream, 0)[0]:
@@ -540,26 +661,33 @@ def main():
     templates = ([mod_template] if two_kernel else []) + [rx_template]
     bps = ([16] if two_kernel else []) + [rx_bps]
     rk = {}
-    for nm, tp, bp, ms in zip(names, templates, bps, kern_ms):
+    build_id = gfdm_amd.build_id()
+    for nm, tp, bp, ms_piped, ms in zip(names, templates, bps, kern_ms, kern_single):
         ach = bp * N * B / (ms * 1e-3) / 1e9
-        tr = pmc_traffic(tp, B)
+        tr = pmc_traffic(tp, B, build_id)
         rk[nm] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                  "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
-                  "kernel": tp, "bytes_per_launch": bp * N * B, "kernel_ms": ms}
+                  "traffic": tr["bytes"], "traffic_source": tr.get("source"), "traffic_note": tr.get("note"),
+                  "kernel": tp, "bytes_per_launch": bp * N * B, "kernel_ms": ms, "kernel_ms_pipelined": ms_piped,
+                  "achieved_pipelined": bp * N * B / (ms_piped * 1e-3) / 1e9, "frac_pipelined": bp * N * B / (ms_piped * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     dominant = max(rk, key=lambda k: rk[k]["kernel_ms"])
     roofline = dict(rk[dominant])
     roofline["kernel"] = "%s (%s, %s family)" % (roofline["kernel"], dominant, dem.kernel_name())
     roofline["copy_ceiling_GBps"] = copy_ceiling(roofline["bytes_per_launch"], a.steps, a.ring_mib, dev)
-    roofline["region"] = ("single-stream replay of the %d timed steps' launches of this kernel back to back, one HIP event pair around the "
-                          "run (launch-to-launch time: kernel + dispatch gap; rocprofv3 kernel time: profiles/README.md)" % a.steps)
+    roofline["region"] = ("kernel_ms / achieved / frac: median of HIP event pairs, one pair per single launch of this kernel over the ring slots; "
+                          "*_pipelined: one event pair around the %d timed steps' launches back to back on one stream "
+                          "(consecutive launches overlap); rocprofv3 kernel time: profiles/README.md" % a.steps)
+    roofline["build_id"] = build_id
+    if world > 1:
+        roofline["rank"] = 0
     result = {
         "metric": cfg["metric"],
         "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall_max / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s; %d QPSK blocks per step %s, ring of %d buffer sets, independent steps pipelined over %d HIP streams"
+        "config": {"workload": "%s; %d QPSK blocks per step %s, ring of %d buffer sets, independent steps pipelined over %d HIP streams%s"
                                % (cfg["workload"], total_per_step if scaling == "strong" else B,
-                                  "in total, sharded contiguously over the GPUs" if scaling == "strong" else "per GPU", ns, S),
+                                  "in total, sharded contiguously over the GPUs" if scaling == "strong" else "per GPU", ns, S,
+                                  "; roofline: rank 0's kernels, cpu_baseline and per-path figures only in the 1-GPU run" if world > 1 else ""),
                    "name": a.config, "block_size": N, "batch_per_gpu": B, "blocks_per_step_all_gpus": total_per_step, "streams": S,
                    "sharding": "independent blocks per GPU (gfdm_amd.sharding.ShardedBatch: one handle + stream per device, contiguous shards), no data-path collective"},
         "msym_per_s": value * N / 1e6,
@@ -583,11 +711,12 @@ def main():
         def measure(name, nbuf, bytes_per_sym, make_fns):
             n_slots = slots(nbuf)
             fns, keep = make_fns(n_slots)
-            w, kms = timed_loop(fns, a.steps, a.warmup, world)
-            gbps = bytes_per_sym * N * B / (kms[0] * 1e-3) / 1e9
+            w, kms, ksingle = timed_loop(fns, a.steps, a.warmup, world)
+            gbps = bytes_per_sym * N * B / (ksingle[0] * 1e-3) / 1e9
             paths[name] = {"blocks_per_s": B * a.steps / w, "msym_per_s": B * a.steps / w * N / 1e6,
-                           "kernel_ms": kms[0], "bytes_per_launch": int(round(bytes_per_sym * N * B)), "achieved_GBps": gbps,
-                           "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "ring_slots": n_slots}
+                           "kernel_ms": ksingle[0], "kernel_ms_pipelined": kms[0], "bytes_per_launch": int(round(bytes_per_sym * N * B)), "achieved_GBps": gbps,
+                           "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "frac_of_hbm_peak_pipelined": bytes_per_sym * N * B / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                           "ring_slots": n_slots}
             del keep
 
         gblock = lambda s: slot_block_start(plan, rank, s)
@@ -637,6 +766,8 @@ def main():
             return [[launcher(s)] for s in range(n_slots)], (fr, rp, o)
 
         measure("frames_zf_ic2_estimated", 2, (8.0 * N + 16.0 * K + 8.0 * A_ * M) / N, mk_chain)
+        if not a.no_host_paths:
+            paths.update(host_batch_paths(cfg, taps, [int(x) for x in a.host_sizes.split(",")], with_cpu=not a.no_cpu_baseline))
         result["paths"] = paths
         result["north_star"] = {"path": "demod_zf_ic2 (BASELINE configs[2]: ZF demod + 2 IC iterations)",
                                 "frac_of_hbm_peak": paths["demod_zf_ic2"]["frac_of_hbm_peak"], "target": 0.40}
@@ -652,7 +783,7 @@ def main():
             o = [torch.empty(BL, N, dtype=torch.complex64, device=dev) for _ in range(nsl)]
             fns = [[raw_launcher(fn, handle, o[sl], [fr[sl], eq[sl]], BL, stream)] for sl in range(nsl)]
             nst = max(10, a.steps // 8)
-            w, kms = timed_loop(fns, nst, 3, world)
+            w, kms, _ = timed_loop(fns, nst, 3, world)
             # beside the back-to-back mean, the median of per-launch event pairs: a sustained run of launches of this size makes some
             # boxes of the pool drop their clocks after a few milliseconds (power cap), and idle gaps make them ramp down as well, so
             # the two figures bracket the kernel's duration
@@ -680,8 +811,10 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
+        result["distributed"] = {"initialized": bool(use_dist), "backend": (a.dist_backend + (" (RCCL)" if a.dist_backend == "nccl" else "")) if use_dist else None,
+                                 "world_size": world, "collectives": "2 barriers per timed loop + 2 all-reduces per statistic (sharding.reduce_stats); no payload collective"}
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

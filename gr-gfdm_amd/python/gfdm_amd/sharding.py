@@ -25,8 +25,9 @@ def output_checksum(out):
 
 
 def reduce_stats(nblocks, checksum, elapsed_s, device):
-    """All-reduce run statistics.  Returns (total blocks, summed checksum[3], max elapsed seconds)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    """All-reduce run statistics.  Returns (total blocks, summed checksum[3], max elapsed seconds).  With an initialised process group the
+    two all-reduces run whatever the world size is (a one-rank RCCL group is how the collective path is exercised on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
         return int(nblocks), checksum.detach().to("cpu"), float(elapsed_s)
     if dist.get_backend() == "gloo":
         device = "cpu"                       # gloo reduces host tensors (the CPU tests; bench.py --dist-backend gloo)
@@ -124,19 +125,41 @@ class ShardedBatch:
 
     def run_global(self, method, global_ins, block_elems):
         """Host batches in, host result out: every global input (a numpy array of total_blocks * block_elems[j] elements) is sliced to the
-        local shards, handed to the kernels (their host entry points copy in, launch, copy out) and the local results are returned with
-        their block range: [(first block, number of blocks, result)].  The caller owns assembling ranks' results, if it wants them at all."""
+        local shards, handed to the kernels' host entry points (gfdm_hostpipe: bounce in chunks or in place) and the local results are
+        returned with their block range: [(first block, number of blocks, result)].  The host entry points block until their result is
+        back, so every local device gets a host thread of its own (ctypes releases the GIL for the duration of the C call) -- the Python
+        twin of gfdm/sharded_batch.h; the first exception of any shard is re-raised after all threads have finished.  The caller owns
+        assembling ranks' results, if it wants them at all."""
+        import threading
         import numpy as np
         first = np.asarray(global_ins[0])
         total = first.size // block_elems[0]
-        out = []
+        work = []
         for i, k in enumerate(self.kernels):
             s, n = self.shard(total, i)
-            if n == 0:
-                continue
-            parts = [np.asarray(g).reshape(total, -1)[s:s + n] for g in global_ins]
-            out.append((s, n, getattr(k, method)(*parts)))
-        return out
+            if n:
+                work.append((k, s, n, [np.asarray(g).reshape(total, -1)[s:s + n] for g in global_ins]))
+        results, errors = [None] * len(work), [None] * len(work)
+
+        def shard_call(j):
+            k, s, n, parts = work[j]
+            try:
+                results[j] = (s, n, getattr(k, method)(*parts))
+            except BaseException as e:       # re-raised on the calling thread
+                errors[j] = e
+
+        if len(work) == 1:
+            shard_call(0)
+        else:
+            threads = [threading.Thread(target=shard_call, args=(j,), name="gfdm-shard-%d" % j) for j in range(len(work))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        for e in errors:
+            if e is not None:
+                raise e
+        return results
 
     def synchronize(self):
         for st in self.streams:

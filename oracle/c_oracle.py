@@ -125,7 +125,7 @@ class COracle:
                                 do_phase_compensation))
 
 
-BENCH_MODE = {"mod_demod": 0, "demod": 1, "demod_ic": 2}
+BENCH_MODE = {"mod_demod": 0, "demod": 1, "demod_ic": 2, "mod": 3}
 
 
 def bench_threads(M, K, L, taps, mode, nthreads, seconds, use_eq=False, ic_iter=0, cpus=None, chunk=32, lib=None):

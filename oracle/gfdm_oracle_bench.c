@@ -18,13 +18,21 @@
 #include <string.h>
 #include <time.h>
 
-enum { BENCH_MOD_DEMOD = 0, BENCH_DEMOD = 1, BENCH_DEMOD_IC = 2 };
+enum { BENCH_MOD_DEMOD = 0, BENCH_DEMOD = 1, BENCH_DEMOD_IC = 2, BENCH_MOD = 3 };
+
+/* start gate: the workers report in once their set-up is done and wait for `go`; `abort` releases them when a worker could not be started
+ * (a pthread barrier cannot be opened with fewer threads than it was initialised for, and waiting on one cannot be cancelled) */
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int arrived, go, abort;
+} gate_t;
 
 typedef struct {
     int M, K, L, ntaps, mode, use_eq, ic_iter, chunk, cpu;
     const float* taps;
     double seconds;        /* length of the timed loop */
-    pthread_barrier_t* ready;   /* every worker (and the driver) waits here once its kernel object and buffers exist */
+    gate_t* gate;          /* every worker waits here once its kernel object and buffers exist */
     double* t_start;       /* CLOCK_MONOTONIC seconds at which the driver saw the barrier open: start of the timed region */
     long blocks;           /* out */
     int failed;            /* out */
@@ -69,11 +77,18 @@ static void* worker(void* arg)
     const float pts[8] = { -a, -a, a, -a, -a, a, a, a };
     if (!w->failed) gfdm_oracle_modulate(o, frames, sym, w->chunk);     /* receiver input: modulated frames (decisions well conditioned) */
     /* set-up (kernel object, buffers, input generation) is NOT timed: the clock starts when every worker has reached this point */
-    pthread_barrier_wait(w->ready);
+    pthread_mutex_lock(&w->gate->mu);
+    ++w->gate->arrived;
+    pthread_cond_broadcast(&w->gate->cv);
+    while (!w->gate->go && !w->gate->abort) pthread_cond_wait(&w->gate->cv, &w->gate->mu);
+    const int aborted = w->gate->abort;
+    pthread_mutex_unlock(&w->gate->mu);
     const double deadline = now_s() + w->seconds;
     long done = 0;
-    if (!w->failed) do {
-        if (w->mode == BENCH_MOD_DEMOD) {
+    if (!w->failed && !aborted) do {
+        if (w->mode == BENCH_MOD) {
+            gfdm_oracle_modulate(o, frames, sym, w->chunk);
+        } else if (w->mode == BENCH_MOD_DEMOD) {
             gfdm_oracle_modulate(o, frames, sym, w->chunk);
             gfdm_oracle_demodulate(o, out, frames, eq, w->chunk);
         } else if (w->mode == BENCH_DEMOD) {
@@ -90,10 +105,10 @@ static void* worker(void* arg)
 }
 
 /* Runs `nthreads` workers for about `seconds`; thread t is pinned to cpus[t] (cpus == NULL: not pinned).
- * mode: 0 modulate + demodulate, 1 demodulate, 2 demodulate + ic_iter IC rounds (QPSK, all subcarriers active);
+ * mode: 0 modulate + demodulate, 1 demodulate, 2 demodulate + ic_iter IC rounds (QPSK, all subcarriers active), 3 modulate;
  * use_eq: with the per-block equaliser vector (generic_work_equalize).  chunk: blocks a worker processes between two looks at
  * the clock.  Returns the blocks processed by all workers (or -1), *elapsed_s = wall time from the moment every worker had finished
- * its set-up (a pthread barrier) to the last join. */
+ * its set-up (the start gate) to the last join. */
 long gfdm_oracle_bench(int timeslots, int subcarriers, int overlap, const float* taps, int ntaps, int mode, int use_eq, int ic_iter,
                        int nthreads, const int* cpus, double seconds, int chunk, double* elapsed_s)
 {
@@ -101,37 +116,40 @@ long gfdm_oracle_bench(int timeslots, int subcarriers, int overlap, const float*
     worker_t* w = (worker_t*)calloc((size_t)nthreads, sizeof(worker_t));
     pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
     if (!w || !th) { free(w); free(th); return -1; }
-    pthread_barrier_t ready;
+    gate_t gate = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0 };
     int started = 0;
     double t0 = 0.0;
     for (int t = 0; t < nthreads; ++t) {
         w[t] = (worker_t){ timeslots, subcarriers, overlap, ntaps, mode, use_eq, ic_iter, chunk, cpus ? cpus[t] : -1, taps,
-                           seconds, &ready, &t0, 0, 0 };
+                           seconds, &gate, &t0, 0, 0 };
     }
-    /* the barrier counts the workers that really start + this thread */
-    if (pthread_barrier_init(&ready, NULL, (unsigned)nthreads + 1) != 0) { free(w); free(th); return -1; }
     for (int t = 0; t < nthreads; ++t) {
         if (pthread_create(&th[t], NULL, worker, &w[t]) != 0) break;
         ++started;
     }
-    if (started < nthreads) {          /* cannot open the barrier with fewer threads: give up cleanly */
-        for (int t = 0; t < started; ++t) pthread_cancel(th[t]);
+    pthread_mutex_lock(&gate.mu);
+    if (started < nthreads) {          /* not every worker exists: release the ones that do and give up cleanly */
+        gate.abort = 1;
+    } else {
+        while (gate.arrived < nthreads) pthread_cond_wait(&gate.cv, &gate.mu);
+        gate.go = 1;
+    }
+    pthread_cond_broadcast(&gate.cv);
+    pthread_mutex_unlock(&gate.mu);
+    t0 = now_s();
+    if (started < nthreads) {
         for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
-        pthread_barrier_destroy(&ready);
         free(w); free(th);
         return -1;
     }
-    pthread_barrier_wait(&ready);
-    t0 = now_s();
     long total = 0;
     int failed = 0;
     for (int t = 0; t < nthreads; ++t) {
-        if (th[t]) pthread_join(th[t], NULL);
+        pthread_join(th[t], NULL);
         total += w[t].blocks;
         failed |= w[t].failed;
     }
     if (elapsed_s) *elapsed_s = now_s() - t0;
-    pthread_barrier_destroy(&ready);
     free(w); free(th);
     return failed ? -1 : total;
 }

@@ -9,6 +9,13 @@ import sys
 
 import pytest
 
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -65,18 +72,54 @@ def test_bench_runs_under_an_external_torchrun_environment():
 def test_roofline_traffic_comes_from_the_committed_pmc_summary():
     """bench.py's `roofline.traffic` is read from the newest profiles/rNN/pmc_hbm_traffic_summary.csv (FETCH_SIZE x 2 + WRITE_SIZE
     per launch), never hard-coded: a row exists for the default configuration's kernels at its batch, the figure is within a few
-    per cent of the algorithmic bytes, and an unprofiled batch gives None."""
+    per cent of the algorithmic bytes, an unprofiled batch gives no figure -- and neither does a summary that was measured with another
+    build of the library (the rows carry gfdm_hip_build_id since round 4): then `traffic` is null and a note says why."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    for kernel, bytes_per_block in (("k_row_modulate<64, 9, 2, 0>", 16 * 576), ("k_row_receive<64, 9, 2, 1, 0, false>", 16 * 576),
-                                    ("k_row_receive<64, 9, 2, 2, 1, true>", 24 * 576)):
+    for kernel, bytes_per_block in (("k_row_modulate<64, 9, 2, 0>", 16 * 576), ("k_row_receive<64, 9, 2, 1, 0, 0>", 16 * 576),
+                                    ("k_row_receive<64, 9, 2, 2, 1, 1>", 24 * 576)):
         tr = bench.pmc_traffic(kernel, 4096)
-        assert tr is not None and tr["source"].startswith("profiles/r")
+        assert tr["bytes"] is not None and tr["source"].startswith("profiles/r")
         assert 1.0 <= tr["bytes"] / (bytes_per_block * 4096) < 1.05
-    assert bench.pmc_traffic("k_row_receive<64, 9, 2, 1, 0, false>", 4097) is None
+        other = bench.pmc_traffic(kernel, 4096, "0123456789abcdef")
+        assert other["bytes"] is None and "build" in other["note"]
+    none = bench.pmc_traffic("k_row_receive<64, 9, 2, 1, 0, 0>", 4097)
+    assert none["bytes"] is None and none["note"]
     assert set(bench.CONFIGS) == {"cfg2", "cfg3", "cfg4", "cfg5"} and bench.CONFIGS["cfg4"]["total"] == bench.CONFIGS["cfg5"]["total"] == 65536
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_process_group_runs_on_the_one_gpu_of_the_box():
+    """torch.distributed over RCCL ("nccl") with ONE rank: process-group initialisation on the device, the barriers around the timed
+    region and the all-reduces of sharding.reduce_stats all execute on the hardware that exists.  Launched the way the driver launches
+    the multi-GPU bench (python -m torch.distributed.run, a child process -- nothing here has touched the GPU) and once through
+    bench.py's own --force-dist; the output checksum equals the plain run's.  No scaling curve is measured by this."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--config", "cfg4", "--batch", "512", "--steps", "3", "--warmup", "1", "--sustained-seconds", "0", "--no-paths", "--no-cpu-baseline",
+              "--ring-mib", "256"]
+    bench_py = os.path.join(ROOT, "bench.py")
+    runs = {"plain": [sys.executable, bench_py] + common,
+            "torchrun": [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port()), bench_py, "--gpus", "1"] + common,
+            "force": [sys.executable, bench_py, "--force-dist"] + common}
+    res = {}
+    for name, cmd in runs.items():
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, (name, p.stderr[-3000:])
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, (name, p.stdout[-2000:])
+        res[name] = json.loads(lines[0])
+    assert all(r["n_gpus"] == 1 for r in res.values())
+    assert res["plain"]["distributed"]["initialized"] is False
+    for name in ("torchrun", "force"):
+        assert res[name]["distributed"]["initialized"] is True and "RCCL" in res[name]["distributed"]["backend"]
+        assert res[name]["output_checksum"] == res["plain"]["output_checksum"]
+        assert res[name]["value"] > 1e6
 
 
 @pytest.mark.gpu

@@ -228,3 +228,42 @@ def test_copy_threads_are_stopped_by_quiesce_and_come_back(pipeline):
     assert g.host_call_stats()["copy_threads"] >= 1 and np.array_equal(a, b)
     with pytest.raises(ValueError):
         g.set_host_pipeline(5, -1, -1, -1)
+
+
+def test_sharded_host_batches_run_their_devices_concurrently(pipeline):
+    """gfdm_amd.sharding.ShardedBatch.run_global (one process driving several GPUs with HOST batches): one host thread per local device, as
+    gr::gfdm::sharded_batch does in C++.  Device 0 listed four times: the results are those of one handle, the wall time is clearly below
+    the sum of the four host calls made one after the other, and a shard's exception reaches the caller after all threads have joined."""
+    import time
+    from gfdm_amd import sharding
+    g = pipeline
+    M, K, L = 9, 64, 2
+    N, total = M * K, 4 * 4096
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    sb = sharding.ShardedBatch(lambda d: g.Demodulator(M, K, L, taps, device=d), [0, 0, 0, 0])
+    x = qpsk(np.random.default_rng(9), (total, N))
+    g.set_host_pipeline(copy_threads=0)          # every shard's thread does its own bounce copies: the test measures the threads of run_global
+    whole = g.Demodulator(M, K, L, taps).demodulate(x)
+    parts = sb.run_global("demodulate", [x], [N])
+    assert [(s, n) for s, n, _ in parts] == [(i * 4096, 4096) for i in range(4)]
+    assert np.array_equal(np.concatenate([p for _, _, p in parts]), whole)
+    serial, threaded = [], []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for i, k in enumerate(sb.kernels):
+            k.demodulate(x[i * 4096:(i + 1) * 4096])
+        serial.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        sb.run_global("demodulate", [x], [N])
+        threaded.append(time.perf_counter() - t0)
+    print("run_global: four host shards of 4096 blocks one after the other %.2f ms, on four threads %.2f ms" % (min(serial) * 1e3, min(threaded) * 1e3))
+    assert min(threaded) < 0.8 * min(serial)
+
+    class Boom(RuntimeError):
+        pass
+
+    def bad(*a):
+        raise Boom("shard failed")
+    sb.kernels[2].demodulate = bad
+    with pytest.raises(Boom):
+        sb.run_global("demodulate", [x], [N])
