@@ -318,9 +318,12 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
             if (jit_parts == 0) jit_parts = receiver ? (1u << gfdm::JIT_PART_RX) : (1u << gfdm::JIT_PART_MOD);
             int mode = g_jit.load();
             if (mode == 3) {
+                // (a receiver may get an estimator attached later, whose preamble-equalised kernels est_attach loads in the foreground:
+                // they count as part of "cached", so that a constructor taken here never leaves a long compile for that call)
+                const unsigned need = jit_parts | (receiver ? (1u << gfdm::JIT_PART_RX_PREAMBLE) : 0u);
                 bool cached = true;
                 for (int part = 0; part < gfdm::JIT_NUM_PARTS; ++part)
-                    if (((jit_parts >> part) & 1u) && !gfdm::jit_cached(M, K, L, part)) cached = false;
+                    if (((need >> part) & 1u) && !gfdm::jit_cached(M, K, L, part)) cached = false;
                 mode = (cached || M <= 16) ? 1 : 2;
             }
             // in the background only if the generic family can serve the shape meanwhile (two tiles of the block in LDS or global scratch)
@@ -782,6 +785,17 @@ int gfdm_hip_advanced_receiver_create(gfdm_hip_advanced_receiver** out, int time
     if ((decision == GFDM_HIP_DECIDE_QPSK && n_points != 4) || (decision == GFDM_HIP_DECIDE_BPSK && n_points != 2)) {
         delete a;
         return fail(GFDM_HIP_EINVAL, "decision rule does not match the number of constellation points");
+    }
+    // The sign-test kernels cancel with the unit constellations' own points (+-1/sqrt 2, +-1).  An explicit QPSK / BPSK rule over other
+    // points (scaled, rotated) keeps its decision REGIONS only if it is the nearest-point rule of those points; it is then run as that, on
+    // the points as given -- every kernel family reads ic.points for it, so a handle gives the same results on each of them.
+    {
+        const float s = 0.70710678118654752f, tol = 1e-6f;
+        auto near = [&](cf p, float re, float im) { return std::fabs(p.x - re) < tol && std::fabs(p.y - im) < tol; };
+        if (decision == GFDM_HIP_DECIDE_QPSK && !(near(pts[0], -s, -s) && near(pts[1], s, -s) && near(pts[2], -s, s) && near(pts[3], s, s)))
+            decision = GFDM_HIP_DECIDE_NEAREST;
+        if (decision == GFDM_HIP_DECIDE_BPSK && !(near(pts[0], -1.f, 0.f) && near(pts[1], 1.f, 0.f)))
+            decision = GFDM_HIP_DECIDE_NEAREST;
     }
 
     const size_t pts_bytes = (size_t)n_points * sizeof(cf);

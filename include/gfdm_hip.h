@@ -53,6 +53,9 @@ typedef enum gfdm_hip_decision {
     GFDM_HIP_DECIDE_NEAREST = 0,   /* minimum Euclidean distance, first minimum wins */
     GFDM_HIP_DECIDE_QPSK = 1,      /* index = 2*(im > 0) + (re > 0)   (constellation_qpsk) */
     GFDM_HIP_DECIDE_BPSK = 2       /* index = (re > 0)                (constellation_bpsk) */
+    /* QPSK / BPSK name the sign tests of GNU Radio's unit constellations, points (+-1 +-j)/sqrt 2 in the order --, +-, -+, ++ and -1, +1.
+     * Given with other points (scaled, rotated) a handle decides by NEAREST over the points as given -- for a scaled QPSK / BPSK the same
+     * regions and the same tie rule (zero -> the first, all-negative point). */
 } gfdm_hip_decision;
 
 typedef struct gfdm_hip_modulator gfdm_hip_modulator;
