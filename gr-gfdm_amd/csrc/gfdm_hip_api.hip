@@ -76,6 +76,9 @@ struct Plan {
     // run-time instantiation in the background (gfdm_hip_set_jit modes 2 / 3): 0 compiling, 1 ready, -1 failed.  While it is 0 the handle
     // runs on the generic family; the first call that sees 1 switches the handle over (a handle is used by one thread at a time)
     std::shared_ptr<std::atomic<int>> jit_pending;
+    // the preamble-equalised receive kernels of a run-time instantiated shape, built in the background after set_channel_estimator when they
+    // are neither cached nor quick to compile: 0 compiling (estimated calls run on the generic family meanwhile), 1 ready, -1 failed (they stay there)
+    std::shared_ptr<std::atomic<int>> jit_pre_pending;
 
     // the family to launch with right now
     int current_family()
@@ -208,9 +211,11 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     }
 
     // Matrix-core form of the cancellation rounds (IcMfma, gfdm_rowlane_impl.h): the A operand of v_mfma_f32_16x16x32_f16, lane l holds
-    // A[row l & 15][k = 8 (l >> 4) + j], j < 8.  Row p = output timeslot; k < 16: high f16 term of a[p][r = k], k >= 16: the residual term of
-    // r = k - 16 (a second operand holds the next residual term), with a[p][r] = -s g[(p - r) mod M] 2^e (s = 1/sqrt 2: the QPSK amplitude; e puts the largest entry near 2^8 so that the
-    // residual terms stay normal f16 numbers).  The decisions enter as +-2^-e, exact in f16.
+    // A[row l & 15][contraction entry 8 (l >> 4) + j], j < 8.  Row p = output timeslot.  Entry 8 cr + j stands for input timeslot r = 4 cr + (j & 3):
+    // the first operand holds the high f16 term of a[p][r] in j < 4 (zero in j >= 4), the second its residual term in j < 4 and the next residual term in j >= 4 --
+    // so that the B operand of lane row cr is made of the decisions of exactly the four timeslots the C / D operand of that lane row holds --
+    // with a[p][r] = -s g[(p - r) mod M] 2^e (s = 1/sqrt 2: the QPSK amplitude; e puts the largest entry near 2^8 so that the residual terms
+    // stay normal f16 numbers).  The decisions enter as +-2^-e, exact in f16.
     size_t icA_off = 0;                     // (behind every other table: the pointers below are offsets into `tables`)
     unsigned ic_sig = 0;
     const int mx_mode = g_ic_mfma.load();
@@ -228,13 +233,13 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
             for (int lane = 0; lane < 64; ++lane) {
                 _Float16 h[8];
                 for (int j = 0; j < 8; ++j) {
-                    const int pr = lane & 15, k = 8 * (lane >> 4) + j, r = k & 15;
+                    const int pr = lane & 15, r = 4 * (lane >> 4) + (j & 3);
                     double a = 0.0;
                     if (pr < M && r < M) a = -s * (double)g_real[((pr - r) % M + M) % M] * c;
                     const _Float16 hi = (_Float16)a;
                     const _Float16 mid = (_Float16)(a - (double)hi);
                     const _Float16 lo = (_Float16)(a - (double)hi - (double)mid);
-                    h[j] = (op == 0) ? ((k < 16) ? hi : mid) : ((k < 16) ? lo : (_Float16)0.0);
+                    h[j] = (op == 0) ? ((j < 4) ? hi : (_Float16)0.0) : ((j < 4) ? mid : lo);
                 }
                 cf packed[2];
                 static_assert(sizeof packed == sizeof h, "8 f16 = 2 complex floats");
@@ -318,12 +323,9 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
             if (jit_parts == 0) jit_parts = receiver ? (1u << gfdm::JIT_PART_RX) : (1u << gfdm::JIT_PART_MOD);
             int mode = g_jit.load();
             if (mode == 3) {
-                // (a receiver may get an estimator attached later, whose preamble-equalised kernels est_attach loads in the foreground:
-                // they count as part of "cached", so that a constructor taken here never leaves a long compile for that call)
-                const unsigned need = jit_parts | (receiver ? (1u << gfdm::JIT_PART_RX_PREAMBLE) : 0u);
                 bool cached = true;
                 for (int part = 0; part < gfdm::JIT_NUM_PARTS; ++part)
-                    if (((need >> part) & 1u) && !gfdm::jit_cached(M, K, L, part)) cached = false;
+                    if (((jit_parts >> part) & 1u) && !gfdm::jit_cached(M, K, L, part)) cached = false;
                 mode = (cached || M <= 16) ? 1 : 2;
             }
             // in the background only if the generic family can serve the shape meanwhile (two tiles of the block in LDS or global scratch)
@@ -397,7 +399,12 @@ hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, cons
 {
     const int family = pl.current_family();
     if (family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
-    if (family == gfdm::FAMILY_ROWLANE_JIT) return gfdm::jit_launch_receive(&pl.jit, pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
+    bool tuned = family == gfdm::FAMILY_ROWLANE_JIT;
+    if (tuned && est && pl.jit_pre_pending) {
+        const int st = pl.jit_pre_pending->load(std::memory_order_acquire);
+        if (st == 1) pl.jit_pre_pending.reset(); else tuned = false;       // still compiling (or failed): this estimated call runs on the generic family
+    }
+    if (tuned) return gfdm::jit_launch_receive(&pl.jit, pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
     return gfdm::launch_generic_receive(pl.dp, ic, est, mode, out, in, f_eq, nblocks, s);
 }
 
@@ -1398,7 +1405,7 @@ int gfdm_hip_channel_estimator_estimate_snr_host(gfdm_hip_channel_estimator* c, 
 
 namespace {
 
-int est_attach(const Plan& pl, const gfdm_hip_channel_estimator*& slot, const gfdm_hip_channel_estimator* c)
+int est_attach(Plan& pl, const gfdm_hip_channel_estimator*& slot, const gfdm_hip_channel_estimator* c)
 {
     if (c && (c->ep.M != pl.dp.M || c->ep.K != pl.dp.K)) {
         char buf[200];
@@ -1407,12 +1414,22 @@ int est_attach(const Plan& pl, const gfdm_hip_channel_estimator*& slot, const gf
         return fail(GFDM_HIP_EINVAL, buf);
     }
     if (c && c->plan.device != pl.device) return fail(GFDM_HIP_EINVAL, "estimator and receiver live on different devices");
-    if (c && pl.family == gfdm::FAMILY_ROWLANE_JIT) {
-        // the preamble-equalised receive kernels of a run-time instantiated shape: compile / load them now rather than in the first call
-        std::string why;
-        DeviceGuard guard(pl.device);
-        if (!gfdm::jit_prepare(pl.dp.M, pl.dp.K, pl.dp.L, 1u << gfdm::JIT_PART_RX_PREAMBLE, why))
-            return fail(GFDM_HIP_EHIP, "run-time instantiation of the preamble-equalised receive kernels failed: " + why);
+    if (c && pl.current_family() == gfdm::FAMILY_ROWLANE_JIT) {
+        // the preamble-equalised receive kernels of a run-time instantiated shape: load them now rather than in the first call -- in the
+        // foreground when that is quick (cached, few timeslots, or gfdm_hip_set_jit(1)), else on the background pool, the estimated calls running
+        // on the generic family until they are there (a handle whose other parts came from gfdm_hip_precompile must not block for a compile here)
+        const int M = pl.dp.M, K = pl.dp.K, L = pl.dp.L;
+        const int mode = g_jit.load();
+        if (mode == 1 || M <= 16 || gfdm::jit_cached(M, K, L, gfdm::JIT_PART_RX_PREAMBLE) || !gfdm::generic_supports(M, K, false)) {
+            std::string why;
+            DeviceGuard guard(pl.device);
+            if (!gfdm::jit_prepare(M, K, L, 1u << gfdm::JIT_PART_RX_PREAMBLE, why))
+                return fail(GFDM_HIP_EHIP, "run-time instantiation of the preamble-equalised receive kernels failed: " + why);
+            pl.jit_pre_pending.reset();
+        } else if (!pl.jit_pre_pending) {
+            pl.jit_pre_pending = std::make_shared<std::atomic<int>>(0);
+            gfdm::jit_prepare_async(M, K, L, 1u << gfdm::JIT_PART_RX_PREAMBLE, pl.device, pl.jit_pre_pending);
+        }
     }
     slot = c;
     return GFDM_HIP_OK;

@@ -52,17 +52,13 @@ constexpr int bpw(int K) { return wg(K) / K; }                               // 
 constexpr int tile_stride(int K, int M) { return K * M + (bpw(K) > 1 ? 16 : 0); }   // complex elements between the tiles of a workgroup
 constexpr size_t lds_bytes(int K, int M) { return (size_t)bpw(K) * (size_t)tile_stride(K, M) * 8 + 64; }
 // Matrix-core form of the interference-cancellation rounds (IcMfma in gfdm_rowlane_impl.h): 64-row aligned wavefronts of whole 16-row
-// groups, a timeslot row within the 16 x 16 tile of v_mfma_f32_16x16x32_f16, and room for the f16 decision image
-// [component][8-timeslot half][K + 2][8] (32 bytes per subcarrier and half) inside the block's own tile.  Blocks that span several
-// wavefronts keep TWO images (one workgroup barrier per round instead of two), which may need more LDS than the tile itself.
+// groups and a timeslot row within the 16 x 16 tile of v_mfma_f32_16x16x32_f16.  Since round 4 the rounds keep everything in registers
+// (lane-row transposes, DPP row shifts); only blocks that span several wavefronts pass each wavefront's two edge rows through LDS:
+// [2 buffers][wavefront][first | last row][component][lane row] x 8 bytes behind the tiles.
 constexpr bool ic_mfma(int K, int M) { return pow2(K) && K >= 16 && M >= 4 && M <= 16; }
-// ... and where it is the default: blocks of one wavefront (K <= 64) exchange their decisions by DPP lane rotates without touching LDS, which
-// measured faster than the matrix-core form (K=64 M=9, 4096 blocks: 12.5 vs 13.7 us); from two wavefronts per block on the decisions cross
-// LDS either way and the matrix cores win (K=128 M=15 L=4, 8192 blocks: 75 -> 66 us)
+// ... and where it is the default (measured, profiles/README.md)
 constexpr bool ic_mfma_preferred(int K, int M) { return ic_mfma(K, M) && K >= 128; }
-constexpr int ic_mfma_halves(int M) { return M > 8 ? 2 : 1; }
-constexpr size_t ic_mfma_image(int K, int M) { return (size_t)32 * ic_mfma_halves(M) * (K + 2); }      // K + 2 rows: wrap-around copies
-constexpr size_t ic_mfma_lds(int K, int M) { return wave_local(K) ? 0 : 2 * ic_mfma_image(K, M) + 64; }
+constexpr size_t ic_mfma_edge_bytes(int K) { return wave_local(K) ? 0 : (size_t)2 * (K / 64) * 2 * 2 * 4 * 8; }
 constexpr int est_stride(int K) { return K + 10; }                           // EQ_PREAMBLE: edge-extended estimate bins per block
 constexpr size_t est_bytes(int K) { return (size_t)bpw(K) * (size_t)est_stride(K) * 8; }
 

@@ -512,46 +512,78 @@ __device__ __forceinline__ cf decide_point(cf x, const IcParams& ic)
 // One round is  d_new[k][p] = d0[k][p] - sum_r g[(p - r) mod M] (dec[k-1][r] + dec[k+1][r]):  per block a product of the M x M circulant
 // of g with an M x 2K matrix of decisions -- the one dense contraction of the receiver.  With QPSK decisions that matrix holds only
 // 0, +-s, +-2s: EXACT in f16.  So the product runs as  D = A B + C  on v_mfma_f32_16x16x32_f16 with
-//   A (16 x 32, per-handle table p.icA) = [ hi | mid ] and [ lo | 0 ], the three-term f16 split of  -s g[(p - r) mod M] 2^e  (33 significant
-//     bits, more than the 24 of the f32 taps themselves: the g[r] largely cancel in the sum, so a two-term split showed 4e-5 relative error
-//     on the degenerate all-zero input; the 32-deep contraction holds two terms against the same 16 decision rows),
-//   B (32 x 16) = the decisions of 16 subcarriers and one component, sigma[k-1] + sigma[k+1] in units of 2^-e, both 8-row halves twice,
+//   A (16 x 32, per-handle table p.icA) = the three-term f16 split hi / mid / lo of  -s g[(p - r) mod M] 2^e  (33 significant bits, more than
+//     the 24 of the f32 taps themselves: the g[r] largely cancel in the sum, so a two-term split showed 4e-5 relative error on the degenerate
+//     all-zero input), hi and mid in one operand, lo in a second,
+//   B (32 x 16) = the decisions of 16 subcarriers and one component, sigma[k-1] + sigma[k+1] in units of 2^-e,
 //   C = d0, D = d_new in f32 (products of f16 values are exact in the f32 accumulator),
-// 16 MFMAs per wavefront (4 groups of 16 subcarriers x re / im x two A operands) and round in place of M(M+1)/2 packed multiply-adds, M(M-1)/2 packed
-// adds and the neighbour moves of the vector-ALU form: at M = 15 the two rounds of BASELINE configs[3] drop from ~1100 vector issue slots
-// per wave to ~250 plus 32 MFMAs that run beside the other waves' vector work.
-// Layouts: C / D lane (cn = lane & 15, cr = lane >> 4) holds subcarrier 16 gi + cn, timeslots 4 cr .. 4 cr + 3; the B operand wants
-// timeslots 8 (cr & 1) .. + 7 of the NEIGHBOUR subcarriers, so the decisions cross LDS once per round as an f16 image
-// [component][half][K][8] in the block's own tile (written 8 bytes, read 16 bytes per lane, conflict free), d0 / the result cross it
-// once before / after the rounds.  Rows p >= M of the 16 x 16 tile are padding: A is zero there, the image holds finite values.
+// 16 MFMAs per wavefront (4 groups of 16 subcarriers x re / im x two A operands) and round in place of M(M+1)/2 packed multiply-adds, M(M-1)/2
+// packed adds and the neighbour moves of the vector-ALU form.
+//
+// Round 4: NOTHING of this crosses LDS any more except the two edge rows of a wavefront in blocks of several wavefronts.
+//   * Contraction index.  Lane (cr = lane >> 4, cn = lane & 15) of the C / D operands holds timeslots 4 cr .. 4 cr + 3 of subcarrier column cn, and
+//     the same lane of B holds contraction entries 8 cr .. 8 cr + 7.  The table maps entry 8 cr + j to timeslot 4 cr + (j & 3), high term for
+//     j < 4 and residual term for j >= 4: the B operand of a lane is then its OWN four decisions, twice -- no exchange between lane rows (the
+//     round-3 layout ran the contraction index straight through the timeslots and needed an f16 image of the block in LDS, written and read
+//     back every round).
+//   * Rows.  Lane row g of a wavefront (16 lanes) is group g of the product.  The kernel runs phase D with the rows of a block PERMUTED over the
+//     lanes -- lane (g, cn) works on row G cn + g of the block's 16 G rows inside this wavefront (G = 4 for K >= 64; row_of) -- so that the
+//     neighbours k - 1 and k + 1 of a group's subcarriers are the SAME lane of groups g - 1 and g + 1; only group 0's lower and group G - 1's
+//     upper neighbour sit one lane over (one DPP row shift each, row rotate where the block ends inside the wavefront).
+//   * d0.  Lane (g, cn) leaves phase D with all M timeslots of its row; the C operand wants lane (cr, cn) to hold timeslots 4 cr .. 4 cr + 3 of
+//     the rows of lanes (0 .. 3, cn): a 4 x 4 transpose between four registers and the four lane rows per timeslot residue and component,
+//     32 v_permlane*_swap (lane_row_transpose4), instead of M b64 LDS writes, a barrier and 32 conflicted reads.
+//   * Blocks of several wavefronts (K >= 128) pass the decisions of each wavefront's first and last row through a small double-buffered LDS
+//     area behind the tiles (128 bytes per wavefront and buffer), one workgroup barrier per round.
+// Rows p >= M of the 16 x 16 tile are padding: A is zero there and in the columns of timeslots >= M, d0 is zero there.
 enum IcKind { ICK_GENERAL = 0, ICK_REALSYM = 1, ICK_MFMA = 2 };
+
+// How d0 reaches the C / D layout of the matrix-core rounds:
+//   true   phase D runs with the block's rows dealt to the lanes in IcMfma's interleaved order and 32 v_permlane*_swap transpose the registers
+//          (no LDS, no barrier) -- but the filter then reads rows 4 apart on neighbouring lanes, a 2-way bank conflict on every one of its
+//          L M b64 reads that no row stride removes (rows = g mod 4 on a lane row leave 8 of the 16 b64 slots of a 16-lane access);
+//   false  phase D keeps the natural order (conflict-free reads); d0 crosses the tile ONCE (M b64 writes, one ordering point, 16 b64 reads in
+//          the interleaved order), the rounds themselves stay in registers.
+// Measured (profiles/r04/ic_mfma_rounds_in_registers.txt): K=128 M=15 L=4 MF + 2 IC per 8192 blocks 71.4 us (true) against 62.7 us of round 3.
+#ifndef GFDM_IC_REG_TRANSPOSE
+#define GFDM_IC_REG_TRANSPOSE 0
+#endif
+constexpr bool kIcRegTranspose = GFDM_IC_REG_TRANSPOSE != 0;
 
 typedef _Float16 ic_h8 __attribute__((ext_vector_type(8)));
 typedef float ic_f4 __attribute__((ext_vector_type(4)));
 
 template <int K, int M> struct IcMfma {
-    static constexpr int NH = rowgeom::ic_mfma_halves(M);
-    static constexpr int PS = (K + 2) * 16;                   // bytes of one [K + 2 rows][8 f16] plane: rows -1 and K are copies of K - 1 and 0
-    static constexpr int IMG = (int)rowgeom::ic_mfma_image(K, M);   // one image = 2 components x NH halves
-    static constexpr bool DB = !rowgeom::wave_local(K);       // two images: ONE workgroup barrier per round
-    // group gi of a wavefront = its lanes' rows 16 gi .. 16 gi + 15: which block of the wavefront (K < 64) and which row inside it
-    static constexpr int grp_block(int gi) { return K < 64 ? (16 * gi) / K : 0; }
-    static constexpr int grp_row(int gi) { return K < 64 ? (16 * gi) % K : 16 * gi; }
+    static constexpr int KW = K < 64 ? K : 64;                // rows of one block inside a wavefront
+    static constexpr int G = KW / 16;                         // 16-row groups (lane rows) per block and wavefront: 1, 2, 4
+    static constexpr int W = K > 64 ? K / 64 : 1;             // wavefronts per block
+    static constexpr bool MULTI = !rowgeom::wave_local(K);    // K >= 128: the wavefronts' edge rows cross LDS, one barrier per round
+    static constexpr int EDGE = (int)rowgeom::ic_mfma_edge_bytes(K) / 2;   // one of the two edge buffers, bytes
+    // the row of its block that lane q of the block works on from phase D on (kIcRegTranspose)
+    static __device__ __forceinline__ int row_of(int q)
+    {
+        if constexpr (!kIcRegTranspose) return q;
+        const int l = q & (KW - 1);
+        return (q - l) + G * (l & 15) + (l >> 4);
+    }
+    // group gi of a wavefront = lane row gi: which block of the wavefront (K < 64) it belongs to
+    static constexpr int grp_block(int gi) { return gi / G; }
     struct Pre {
-        uint4 a, a2;           // A operands of this lane: [high | residual] and [second residual | 0]
-        float sig[4];          // per 16-subcarrier group: the decision magnitude 2^-e, 0 on an inactive subcarrier
+        uint4 a, a2;           // A operands of this lane: [high | 0] and [residual | second residual] of its four timeslots
+        float sig[4];          // per group: the decision magnitude 2^-e, 0 on an inactive subcarrier
     };
 
     // requested with the other tables at the start of the kernel
     static __device__ __forceinline__ void preload(Pre& pre, const DevicePlan& p, const IcParams& ic)
     {
-        const int lane = threadIdx.x & 63, r0 = (threadIdx.x & ~63) + (lane & 15);
+        const int lane = threadIdx.x & 63, cn = lane & 15;
+        const int wbase = (K > 64) ? ((threadIdx.x & ~63) & (K - 1)) : 0;      // first row of this wavefront inside its block
         pre.a = reinterpret_cast<const uint4*>(p.icA)[lane];
         pre.a2 = reinterpret_cast<const uint4*>(p.icA)[64 + lane];
         const float sig = (float)__builtin_bit_cast(_Float16, (unsigned short)p.ic_sig);      // 2^-e, carried as its f16 bit pattern
         static_for<0, 4>([&](auto gi) {
             constexpr int g4 = decltype(gi)::value;
-            pre.sig[g4] = ic.active[(r0 + 16 * g4) & (K - 1)] ? sig : 0.f;
+            pre.sig[g4] = ic.active[wbase + G * cn + (g4 % G)] ? sig : 0.f;
         });
     }
 
@@ -565,91 +597,118 @@ template <int K, int M> struct IcMfma {
         return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(y0, y1));
     }
 
-    // d: row q of the block after matched filter + inverse DFT.  Leaves the block after ic_iter rounds in its tile X, [k][M], synchronised.
-    template <int TS>
-    static __device__ __forceinline__ void rounds(unsigned char* smem, cf* X, int q, const cf (&d)[M], const Pre& pre, int ic_iter)
+    // lane cn <- lane cn - 1 / cn + 1 of its 16-lane row (DPP row_shr:1 = 0x111, row_shl:1 = 0x101, row_ror:n = 0x120 + n).  A block that ends
+    // inside the wavefront wraps around inside the row (rotate); otherwise the lane at the end of the row takes `fill` (the neighbouring
+    // wavefront's edge row).
+    static __device__ __forceinline__ unsigned from_below(unsigned v, unsigned fill)
     {
-        static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = d[m]; });
-        block_sync<K>();
+        if constexpr (MULTI) return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x111, 0xF, 0xF, false);
+        else return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xF, 0xF, false);
+    }
+    static __device__ __forceinline__ unsigned from_above(unsigned v, unsigned fill)
+    {
+        if constexpr (MULTI) return (unsigned)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x101, 0xF, 0xF, false);
+        else return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x12F, 0xF, 0xF, false);
+    }
+    static __device__ __forceinline__ unsigned add_h2(unsigned a, unsigned b)
+    {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, a) + __builtin_bit_cast(h2, b));
+    }
+
+    // d: row row_of(q) of the block after matched filter + inverse DFT.  Leaves the block after ic_iter rounds in its tile, [k][M], synchronised.
+    // `edge`: the workgroup's edge-row area (MULTI only).  TS: tile stride of the workgroup's blocks in complex elements.
+    template <int TS>
+    static __device__ __forceinline__ void rounds(unsigned char* smem, unsigned char* edge, cf* X, int q, const cf (&d)[M], const Pre& pre, int ic_iter)
+    {
         const int lane = threadIdx.x & 63, cn = lane & 15, cr = lane >> 4;
-        const int wrow = threadIdx.x & ~63;                   // first row of this wavefront in the workgroup's lane space
-        const int n0 = (K < 64) ? cn : ((wrow & (K - 1)) + cn);   // row of group 0's lane inside its block
+        const int wrow = threadIdx.x & ~63;                   // first lane of this wavefront in the workgroup's lane space
+        const int wbase = (K > 64) ? (wrow & (K - 1)) : 0;    // first row of this wavefront inside its block
         unsigned char* blk0 = smem + (size_t)(wrow / K) * TS * sizeof(cf);     // tile of the wavefront's first block
         const ic_h8 afrag = __builtin_bit_cast(ic_h8, pre.a), afrag2 = __builtin_bit_cast(ic_h8, pre.a2);
-        // d0 in the C / D layout: timeslots 4 cr .. 4 cr + 3 of subcarrier n0 + 16 gi, real and imaginary parts apart.  (Timeslots >= M
-        // read whatever follows in the tile: padding rows of the 16 x 16 product, never stored.)
         ic_f4 c0[4][2], cur[4][2];
-        {
-            const float* xf = reinterpret_cast<const float*>(blk0) + 2 * (n0 * M + 4 * cr);
-            static_for<0, 4>([&](auto gi) {
-                constexpr int g4 = decltype(gi)::value;
-                constexpr int off = grp_block(g4) * TS * 2 + grp_row(g4) * M * 2;          // in floats
-                static_for<0, 4>([&](auto ii) {
-                    constexpr int i = decltype(ii)::value;
-                    c0[g4][0][i] = xf[off + 2 * i];
-                    c0[g4][1][i] = xf[off + 2 * i + 1];
-                });
-                cur[g4][0] = c0[g4][0];
-                cur[g4][1] = c0[g4][1];
-            });
-        }
-        block_sync<K>();                                      // everyone holds its part of d0: the tile becomes the decision image
-        // image addresses: ONE base per lane for the writes and one for the reads, everything else is an immediate offset
-        //   write: row n + 1 (rows 0 and K + 1 are the wrap-around copies), half cr >> 1, timeslots 4 (cr & 1) .. + 3 of that half
-        //   read:  rows n and n + 2 (= subcarriers n - 1 and n + 1), half cr & 1
-        unsigned char* wbase = blk0 + (NH == 2 ? (cr >> 1) * PS : 0) + (n0 + 1) * 16 + 8 * (cr & 1);
-        const unsigned char* rbase = blk0 + (NH == 2 ? (cr & 1) * PS : 0) + n0 * 16;
-        const bool wave_first = (K <= 64) || ((wrow & (K - 1)) == 0), wave_last = (K <= 64) || ((wrow & (K - 1)) == K - 64);
-        for (int it = 0; it < ic_iter; ++it) {                                                           // adv:56-76
-            const int img_off = DB ? (it & 1) * IMG : 0;
-            static_for<0, 4>([&](auto gi) {
-                constexpr int g4 = decltype(gi)::value;
-                constexpr int goff = grp_block(g4) * TS * (int)sizeof(cf) + grp_row(g4) * 16;
-                const float sig = pre.sig[g4];
-                static_for<0, 2>([&](auto ci) {
-                    constexpr int c = decltype(ci)::value;
-                    const uint2 w = make_uint2(decide2(cur[g4][c][0], cur[g4][c][1], sig), decide2(cur[g4][c][2], cur[g4][c][3], sig));
-                    if (NH == 2 || cr < 2) {
-                        unsigned char* dst = wbase + img_off + goff + c * NH * PS;
-                        *reinterpret_cast<uint2*>(dst) = w;
-                        // wrap-around copies: subcarrier 0 again behind K - 1, subcarrier K - 1 again in front of 0
-                        if constexpr (grp_row(g4) == 0) { if (wave_first && cn == 0) *reinterpret_cast<uint2*>(dst + K * 16) = w; }
-                        if constexpr (grp_row(g4) + 16 == K || (K >= 64 && g4 == 3)) { if (wave_last && cn == 15) *reinterpret_cast<uint2*>(dst - K * 16) = w; }
-                    }
-                });
-            });
+        if constexpr (!kIcRegTranspose) {
+            // d0 through the block's tile: rows in natural order in, timeslots 4 cr .. 4 cr + 3 of rows wbase + G cn + g out
+            static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = d[m]; });
             block_sync<K>();
             static_for<0, 4>([&](auto gi) {
                 constexpr int g4 = decltype(gi)::value;
-                constexpr int goff = grp_block(g4) * TS * (int)sizeof(cf) + grp_row(g4) * 16;
-                static_for<0, 2>([&](auto ci) {
-                    constexpr int c = decltype(ci)::value;
-                    // neighbours k - 1 and k + 1 (wrap mod K through the copies)                                rx:274-299
-                    const unsigned char* src = rbase + img_off + goff + c * NH * PS;
-                    const ic_h8 below = *reinterpret_cast<const ic_h8*>(src);
-                    const ic_h8 above = *reinterpret_cast<const ic_h8*>(src + 32);
-                    const ic_h8 nb = below + above;
-                    cur[g4][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag2, nb, c0[g4][c], 0, 0, 0);      // smallest terms first
-                    cur[g4][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, nb, cur[g4][c], 0, 0, 0);
-                });
-            });
-            if constexpr (!DB) block_sync<K>();               // all neighbour reads done before the image is rewritten
-        }
-        if constexpr (DB) block_sync<K>();                    // the last image has been read by everyone: the tile takes the result
-        {
-            float* xf = reinterpret_cast<float*>(blk0) + 2 * (n0 * M + 4 * cr);
-            static_for<0, 4>([&](auto gi) {
-                constexpr int g4 = decltype(gi)::value;
-                constexpr int off = grp_block(g4) * TS * 2 + grp_row(g4) * M * 2;
+                const cf* row = reinterpret_cast<const cf*>(blk0) + grp_block(g4) * TS + (wbase + G * cn + (g4 % G)) * M + 4 * cr;
                 static_for<0, 4>([&](auto ii) {
                     constexpr int i = decltype(ii)::value;
-                    if (12 + i < M || 4 * cr + i < M) {            // (first form: known at compile time for every lane)
-                        xf[off + 2 * i] = cur[g4][0][i];
-                        xf[off + 2 * i + 1] = cur[g4][1][i];
-                    }
+                    cf v = mk(0.f, 0.f);
+                    if (12 + i < M || 4 * cr + i < M) v = row[i];
+                    c0[g4][0][i] = v.x;
+                    c0[g4][1][i] = v.y;
+                });
+            });
+            block_sync<K>();                                  // everyone holds its part of d0: the tile is free for the result
+        } else
+        // d0 in the C / D layout: register (4 j + i) of lane row g  ->  register i of group g on lane row j, for both components
+        static_for<0, 4>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            static_for<0, 2>([&](auto ci) {
+                constexpr int c = decltype(ci)::value;
+                float t[4];
+                static_for<0, 4>([&](auto ji) {
+                    constexpr int j = decltype(ji)::value;
+                    if constexpr (4 * j + i < M) t[j] = c ? d[4 * j + i].y : d[4 * j + i].x; else t[j] = 0.f;
+                });
+                lane_row_transpose4(t[0], t[1], t[2], t[3]);
+                static_for<0, 4>([&](auto gi) { constexpr int g4 = decltype(gi)::value; c0[g4][c][i] = t[g4]; });
+            });
+        });
+        static_for<0, 4>([&](auto gi) { constexpr int g4 = decltype(gi)::value; cur[g4][0] = c0[g4][0]; cur[g4][1] = c0[g4][1]; });
+        const int wave = wrow / 64 % W;                       // this wavefront's place in its block (MULTI)
+        for (int it = 0; it < ic_iter; ++it) {                                                           // adv:56-76
+            uint2 w[4][2];
+            static_for<0, 4>([&](auto gi) {
+                constexpr int g4 = decltype(gi)::value;
+                const float sig = pre.sig[g4];
+                static_for<0, 2>([&](auto ci) {
+                    constexpr int c = decltype(ci)::value;
+                    w[g4][c] = make_uint2(decide2(cur[g4][c][0], cur[g4][c][1], sig), decide2(cur[g4][c][2], cur[g4][c][3], sig));
+                });
+            });
+            uint2 fill_lo[2] = { make_uint2(0u, 0u), make_uint2(0u, 0u) }, fill_hi[2] = { make_uint2(0u, 0u), make_uint2(0u, 0u) };
+            if constexpr (MULTI) {
+                // this wavefront's first row is (group 0, cn 0), its last (group 3, cn 15): [buffer][wavefront][first | last][component][cr]
+                uint2* eb = reinterpret_cast<uint2*>(edge + (it & 1) * EDGE);
+                if (cn == 0) { eb[(wave * 2 + 0) * 8 + cr] = w[0][0]; eb[(wave * 2 + 0) * 8 + 4 + cr] = w[0][1]; }
+                if (cn == 15) { eb[(wave * 2 + 1) * 8 + cr] = w[3][0]; eb[(wave * 2 + 1) * 8 + 4 + cr] = w[3][1]; }
+                block_sync<K>();
+                const int below = (wave + W - 1) % W, above = (wave + 1) % W;                            // wrap mod K: rx:274-299
+                fill_lo[0] = eb[(below * 2 + 1) * 8 + cr]; fill_lo[1] = eb[(below * 2 + 1) * 8 + 4 + cr];
+                fill_hi[0] = eb[(above * 2 + 0) * 8 + cr]; fill_hi[1] = eb[(above * 2 + 0) * 8 + 4 + cr];
+            }
+            static_for<0, 4>([&](auto gi) {
+                constexpr int g4 = decltype(gi)::value;
+                constexpr int b0 = (g4 / G) * G, j = g4 % G;          // first group of this group's block, place inside it
+                static_for<0, 2>([&](auto ci) {
+                    constexpr int c = decltype(ci)::value;
+                    // neighbours k - 1 and k + 1                                                               rx:274-299
+                    uint2 lo, hi;
+                    if constexpr (j > 0) lo = w[g4 - 1][c];
+                    else lo = make_uint2(from_below(w[b0 + G - 1][c].x, fill_lo[c].x), from_below(w[b0 + G - 1][c].y, fill_lo[c].y));
+                    if constexpr (j < G - 1) hi = w[g4 + 1][c];
+                    else hi = make_uint2(from_above(w[b0][c].x, fill_hi[c].x), from_above(w[b0][c].y, fill_hi[c].y));
+                    const unsigned n0 = add_h2(lo.x, hi.x), n1 = add_h2(lo.y, hi.y);
+                    const ic_h8 nb = __builtin_bit_cast(ic_h8, make_uint4(n0, n1, n0, n1));
+                    // the high terms first: where they cancel (small d0) the residual terms are then added to a small sum and keep their bits
+                    cur[g4][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, nb, c0[g4][c], 0, 0, 0);
+                    cur[g4][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag2, nb, cur[g4][c], 0, 0, 0);
                 });
             });
         }
+        // result -> the tile in natural order [k][M]: group g4 of lane (cr, cn) is row wbase + G cn + g4 % G of block grp_block(g4)
+        static_for<0, 4>([&](auto gi) {
+            constexpr int g4 = decltype(gi)::value;
+            cf* row = reinterpret_cast<cf*>(blk0) + grp_block(g4) * TS + (wbase + G * cn + (g4 % G)) * M + 4 * cr;
+            static_for<0, 4>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                if (12 + i < M || 4 * cr + i < M) row[i] = mk(cur[g4][0][i], cur[g4][1][i]);     // (first form: known at compile time for every lane)
+            });
+        });
         block_sync<K>();
     }
 };
@@ -736,7 +795,7 @@ __global__ __launch_bounds__(RowShape<K>::WG, (MODE == RX_IC && ICK == ICK_MFMA)
     // The equaliser vector is needed only after the subcarrier FFT: request it now, behind every wave's sample loads
     // (HBM serves requests roughly in issue order, so the samples of all waves arrive first and the transforms start
     // earlier; f_eq streams in while phases A/B run).
-    constexpr bool ROWREG = (K == 64 && L == 2 && EQ == EQ_PREAMBLE);   // equalised row stays in registers between phases C and D
+    constexpr bool ROWREG = (K == 64 && L == 2 && EQ == EQ_PREAMBLE && !(ICMX && kIcRegTranspose));   // equalised row stays in registers between phases C and D
     cf xrow[ROWREG ? M : 1];
     cf heq[EQ == EQ_VECTOR ? M : 1];
     if constexpr (EQ == EQ_VECTOR) {
@@ -805,11 +864,14 @@ __global__ __launch_bounds__(RowShape<K>::WG, (MODE == RX_IC && ICK == ICK_MFMA)
     }
 
     // ---- phase D: S[k][m] = sum_i taps[((i + L/2) % L) M + m] X[(k + i - L/2) mod K][m]                      rx:165-192
+    // (the matrix-core rounds want the rows of a block dealt to the lanes in IcMfma's order: kq instead of q from here to the rounds)
+    int kq = q;
+    if constexpr (ICMX) kq = IcMfma<K, M>::row_of(q);
     cf s[M];
     static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; s[m] = mk(0.f, 0.f); });
     auto filter = [&](auto real_tag) {                     // one copy per kind of taps, chosen by a uniform branch
         constexpr bool TREAL = decltype(real_tag)::value;
-        if constexpr (K == 64 && L == 2) {
+        if constexpr (K == 64 && L == 2 && !(ICMX && kIcRegTranspose)) {
             // the block IS the wavefront and the only foreign row is k - 1 = lane k - 1: a DPP wave rotate of the own row replaces the
             // second LDS row read
             const cf* rb = X + q * MS;
@@ -824,7 +886,7 @@ __global__ __launch_bounds__(RowShape<K>::WG, (MODE == RX_IC && ICK == ICK_MFMA)
         } else {
             static_for<0, L>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
-                const cf* rb = X + wrap_k<K>(q + i - L / 2 + K) * MS;
+                const cf* rb = X + wrap_k<K>(kq + i - L / 2 + K) * MS;
                 static_for<0, M>([&](auto mi) {
                     constexpr int m = decltype(mi)::value;
                     s[m] = tap_fma<TREAL>(tap(std::integral_constant<int, ((i + L / 2) % L) * M + m>{}), rb[m], s[m]);
@@ -844,7 +906,8 @@ __global__ __launch_bounds__(RowShape<K>::WG, (MODE == RX_IC && ICK == ICK_MFMA)
     GFDM_STAMP(3);
 
     if constexpr (ICMX) {
-        IcMfma<K, M>::template rounds<T::TS>(smem, X, q, d, icpre, ic_iter);
+        constexpr size_t edge_off = (EQ == EQ_PREAMBLE) ? row_lds_bytes<K, MS>() + EstTile<K>::bytes : row_lds_bytes<K, M>();
+        IcMfma<K, M>::template rounds<T::TS>(smem, smem + edge_off, X, q, d, icpre, ic_iter);
     } else if constexpr (MODE == RX_IC) {
         // One cancellation round of the reference is  d_new = IDFT_M(S - ic (.) DFT_M(nb)) / M  with nb = dec_{k-1} + dec_{k+1}.
         // Both transforms are linear, so  d_new = d0 - g (*) nb  with d0 = IDFT_M(S)/M (already in d) and the M-tap circular
@@ -1097,8 +1160,7 @@ hipError_t launch_rx(const DevicePlan& p, const IcParams& ic, const EstPlan* est
     const EstPlan& e = est ? *est : kNoEst;
     const bool pre = (PART == 2) || (PART == 4 && est);                          // EQ_PREAMBLE: two more tile columns + the estimate behind the tiles
     size_t lds = pre ? row_lds_bytes<K, M + 2>() + EstTile<K>::bytes : row_lds_bytes<K, M>();
-    if (PART == 4 && lds < rowgeom::ic_mfma_lds(K, M)) lds = rowgeom::ic_mfma_lds(K, M);
-    if (PART == 4) lds += 128;            // the padding rows of the 16 x 16 tiles read up to 11 values past the last row
+    if (PART == 4) lds += rowgeom::ic_mfma_edge_bytes(K);       // behind everything else: the wavefronts' edge rows of the IcMfma rounds
 #define GFDM_RX(MODE_, EQ_, ICK_)                                                                                                       \
     do {                                                                                                                            \
         if (lds > 64 * 1024) {      /* only the largest shape with the estimate behind its tile */                                 \

@@ -316,7 +316,9 @@ int gfdm_hip_channel_estimator_estimate_snr_device(gfdm_hip_channel_estimator* c
  * examples/hier_gfdm_receiver.grc in ONE kernel: the receiver kernel runs estimate_frame on its block's received preamble
  * and applies the result as its one-tap equaliser; the N-bin estimate never exists in HBM (the preamble's 2 * fft_len samples
  * are read instead of N equaliser bins).  Results equal estimate_frame followed by generic_work_equalize.
- * set_channel_estimator: the estimator handle must match (timeslots, subcarriers, device) and outlive its use; NULL detaches.
+ * set_channel_estimator: the estimator handle must match (timeslots, subcarriers, device) and outlive its use; NULL detaches.  (A receiver on
+ *   run-time instantiated kernels loads its preamble-equalised kernels here: at once when they are cached or quick to build, otherwise on the
+ *   background pool -- the estimated calls run on the generic kernel family, same results, until they are there.)
  * rx_preamble: preamble of block b at rx_preamble + b * preamble_stride complex (0 = packed, 2 * fft_len) -- a burst buffer
  *   holding preamble and frame back to back is passed as `in` and, offset to the core preamble, as `rx_preamble`.
  * The block I/O follows configure_frames when that was called (frames in, demapped symbols out, noutput_size as there),

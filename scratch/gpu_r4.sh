@@ -51,5 +51,32 @@ pmc)
   done
   python3 $R/scratch/pmc_summary.py $O/pmc $id > $O/pmc_hbm_traffic_summary.csv; rm -rf $O/pmc
   grep -E "k_row_receive|^run" $O/pmc_hbm_traffic_summary.csv | head -40 ;;
+ic)     # the interference-cancellation kernels: parity first, then durations with the rounds on the matrix cores / vector ALU
+  cd $R
+  timeout 1500 python -m pytest tests/test_parity_gpu.py -x -q -k "ic or matrix or zero or golden or full_size" > $O/pytest_ic.txt 2>&1; echo "rc=$?" >> $O/pytest_ic.txt; tail -4 $O/pytest_ic.txt
+  cd /tmp
+  echo "label,kernel,workgroups,workgroup_size,queue,launches,mean_us,median_us,min_us,max_us" > $O/ic_kernels.csv
+  for mx in 1 0 2; do
+    for b in 8192 65536; do GFDM_MX=$mx trace $O/ic_kernels.csv 128_15_4_mx${mx}_mf_ic2_$b 20 demod_mf_ic2 $b 40 2 128 15 4; GFDM_MX=$mx trace $O/ic_kernels.csv 128_15_4_mx${mx}_zf_ic2_$b 20 demod_zf_ic2 $b 40 2 128 15 4; done
+    for b in 4096 65536; do reps=400; slots=36; [ $b = 65536 ] && { reps=60; slots=3; }
+      GFDM_MX=$mx trace $O/ic_kernels.csv 64_9_2_mx${mx}_mf_ic2_$b $((reps / 2)) demod_mf_ic2 $b $reps $slots; GFDM_MX=$mx trace $O/ic_kernels.csv 64_9_2_mx${mx}_zf_ic2_$b $((reps / 2)) demod_zf_ic2 $b $reps $slots; done
+  done
+  trace $O/ic_kernels.csv 128_15_4_mf_8192 20 demod_mf 8192 40 2 128 15 4; trace $O/ic_kernels.csv 128_15_4_mf_65536 20 demod_mf 65536 40 2 128 15 4
+  cut -d, -f1-2,7-9 $O/ic_kernels.csv ;;
+icab)   # same-box A/B of the cancellation kernels: working tree, the register-transpose variant (scratch/ab/regx), round 3 (scratch/ab/r3 + its package)
+  echo "label,kernel,workgroups,workgroup_size,queue,launches,mean_us,median_us,min_us,max_us" > $O/ic_ab.csv
+  for rep in 1 2; do
+  for v in tree regx r3; do
+    unset GFDM_HIP_LIB GFDM_PKG
+    [ $v = regx ] && export GFDM_HIP_LIB=$R/scratch/ab/regx/libgfdm_hip.so
+    [ $v = r3 ] && export GFDM_HIP_LIB=$R/scratch/ab/r3/libgfdm_hip.so GFDM_PKG=$R/scratch/old_pkg
+    for b in 8192 65536; do trace $O/ic_ab.csv ${v}_128_15_4_mf_ic2_${b}_$rep 20 demod_mf_ic2 $b 40 2 128 15 4; trace $O/ic_ab.csv ${v}_128_15_4_zf_ic2_${b}_$rep 20 demod_zf_ic2 $b 40 2 128 15 4; done
+    GFDM_MX=2 trace $O/ic_ab.csv ${v}_64_9_2_mx2_mf_ic2_4096_$rep 200 demod_mf_ic2 4096 400 36
+    GFDM_MX=2 trace $O/ic_ab.csv ${v}_64_9_2_mx2_zf_ic2_4096_$rep 200 demod_zf_ic2 4096 400 36
+  done; done
+  unset GFDM_HIP_LIB GFDM_PKG
+  trace $O/ic_ab.csv tree_64_9_2_dpp_mf_ic2_4096 200 demod_mf_ic2 4096 400 36
+  cut -d, -f1,7-9 $O/ic_ab.csv
+  cd $R; timeout 900 python -m pytest tests/test_parity_gpu.py -x -q -k "ic or matrix or zero or golden" > $O/pytest_ic.txt 2>&1; tail -3 $O/pytest_ic.txt ;;
 *) echo "unknown task $1"; exit 2 ;;
 esac
