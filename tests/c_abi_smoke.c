@@ -1,8 +1,11 @@
 /* A C99 caller of the boundary: links libgfdm_hip.so through include/gfdm_hip.h only (tests/test_boundary.py builds and runs it).
  * Without a GPU every create must fail with GFDM_HIP_ENODEV (no CPU fallback); with one, a K=4 M=3 block goes through the
- * modulator and the receiver (error codes, determinism of the arithmetic under scaling). */
+ * modulator and the receiver (error codes, determinism of the arithmetic under scaling), and a run of blocks goes through buffers
+ * registered once with gfdm_hip_register_host -- what a GNU Radio block does with its long-lived circular buffers -- which the host
+ * calls then use in place (gfdm_hip_host_call_stats), with the results of the bounced call. */
 #include <gfdm_hip.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 int main(void)
@@ -41,8 +44,28 @@ int main(void)
             if (out2[i] != 2.0f * out[i]) { printf("not linear at %d: %g vs %g\n", i, out2[i], 2.0f * out[i]); return 27; }
         if (!(energy > 0.0f)) return 28;
     }
+    {   /* a scheduler's buffers: allocated once, registered once, any run of blocks inside them per call */
+        enum { NB = 700 };
+        const size_t bytes = (size_t)NB * N * 2 * sizeof(float);
+        float* ring_in = (float*)malloc(bytes);
+        float* ring_out = (float*)malloc(bytes);
+        float* plain_out = (float*)malloc(bytes);
+        int64_t chunks = 0, staged = 0;
+        unsigned direct = 0;
+        if (!ring_in || !ring_out || !plain_out) return 30;
+        for (i = 0; i < NB * N * 2; ++i) ring_in[i] = mid[i % (2 * N)] * (float)(1 + i % 5);
+        if (gfdm_hip_receiver_demodulate_host(rx, plain_out, ring_in, NULL, NB) != GFDM_HIP_OK) return 31;          /* pageable: bounced */
+        if (gfdm_hip_host_call_stats(&chunks, NULL, &staged, &direct, NULL, NULL) != GFDM_HIP_OK || direct != 0 || staged != (int64_t)(2 * bytes)) return 32;
+        if (gfdm_hip_register_host(ring_in, bytes) != GFDM_HIP_OK || gfdm_hip_register_host(ring_out, bytes) != GFDM_HIP_OK) { printf("register: %s\n", gfdm_hip_last_error()); return 33; }
+        if (gfdm_hip_receiver_demodulate_host(rx, ring_out + 2 * N * 3, ring_in + 2 * N * 3, NULL, NB - 3) != GFDM_HIP_OK) return 34;   /* a run inside the buffers */
+        if (gfdm_hip_host_call_stats(&chunks, NULL, &staged, &direct, NULL, NULL) != GFDM_HIP_OK || direct != 3u || staged != 0 || chunks != 1) return 35;
+        if (memcmp(ring_out + 2 * N * 3, plain_out + 2 * N * 3, bytes - (size_t)3 * N * 2 * sizeof(float)) != 0) return 36;
+        if (gfdm_hip_unregister_host(ring_in) != GFDM_HIP_OK || gfdm_hip_unregister_host(ring_out) != GFDM_HIP_OK) return 37;
+        if (gfdm_hip_unregister_host(ring_in) == GFDM_HIP_OK) return 38;                                             /* not registered any more */
+        free(ring_in); free(ring_out); free(plain_out);
+    }
     gfdm_hip_modulator_destroy(mod);
     gfdm_hip_receiver_destroy(rx);
-    printf("modulate + demodulate ok\n");
+    printf("modulate + demodulate ok, registered buffers used in place\n");
     return 0;
 }
