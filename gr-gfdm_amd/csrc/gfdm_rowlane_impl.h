@@ -544,7 +544,8 @@ enum IcKind { ICK_GENERAL = 0, ICK_REALSYM = 1, ICK_MFMA = 2 };
 //          L M b64 reads that no row stride removes (rows = g mod 4 on a lane row leave 8 of the 16 b64 slots of a 16-lane access);
 //   false  phase D keeps the natural order (conflict-free reads); d0 crosses the tile ONCE (M b64 writes, one ordering point, 16 b64 reads in
 //          the interleaved order), the rounds themselves stay in registers.
-// Measured (profiles/r04/ic_mfma_rounds_in_registers.txt): K=128 M=15 L=4 MF + 2 IC per 8192 blocks 71.4 us (true) against 62.7 us of round 3.
+// Measured on one box (profiles/r04/ic_mfma_rounds_in_registers.txt, rocprofv3 means): K=128 M=15 L=4 MF + 2 IC per 8192 blocks 67.4 us (true), 62.5 us
+// (false), 63.7 us with round 3's LDS image; per 65 536 blocks 517 / 487 / 498 us.
 #ifndef GFDM_IC_REG_TRANSPOSE
 #define GFDM_IC_REG_TRANSPOSE 0
 #endif

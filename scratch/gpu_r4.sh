@@ -51,6 +51,17 @@ pmc)
   done
   python3 $R/scratch/pmc_summary.py $O/pmc $id > $O/pmc_hbm_traffic_summary.csv; rm -rf $O/pmc
   grep -E "k_row_receive|^run" $O/pmc_hbm_traffic_summary.csv | head -40 ;;
+sq)     # SQ / LDS counters per wave (two passes of eight counters), with the build id
+  rm -rf $O/sq; mkdir -p $O/sq
+  id=$(python3 -c "import sys; sys.path.insert(0, '$R/gr-gfdm_amd/python'); import gfdm_amd; print(gfdm_amd.build_id())")
+  for spec in "modulate 4096 64 9 2 1" "demod_mf 4096 64 9 2 1" "demod_mf_ic2 4096 64 9 2 1" "demod_zf_ic2 4096 64 9 2 1" "demod_zf_ic2 65536 64 9 2 1" \
+              "demod_mf 8192 128 15 4 1" "demod_mf_ic2 8192 128 15 4 1" "demod_mf_ic2 8192 128 15 4 0" "demod_zf 8192 256 31 2 1"; do
+    set -- $spec; run=$1_$3_$4_$5_$2; [ $6 = 0 ] && run=${run}_valu; reps=40; [ $2 -ge 65536 ] && reps=12
+    GFDM_MX=$6 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $O/sq/$run/a -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
+    GFDM_MX=$6 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA --output-format csv -d $O/sq/$run/b -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
+  done
+  python3 $R/scratch/pmc_summary.py $O/sq $id > $O/pmc_sq_counters_summary.csv; rm -rf $O/sq
+  grep -c . $O/pmc_sq_counters_summary.csv ;;
 ic)     # the interference-cancellation kernels: parity first, then durations with the rounds on the matrix cores / vector ALU
   cd $R
   timeout 1500 python -m pytest tests/test_parity_gpu.py -x -q -k "ic or matrix or zero or golden or full_size" > $O/pytest_ic.txt 2>&1; echo "rc=$?" >> $O/pytest_ic.txt; tail -4 $O/pytest_ic.txt
