@@ -28,7 +28,10 @@ constexpr size_t kSingleChunkMax = 1u << 20;    // a call that stages at most th
 constexpr size_t kAutoMin = 512u << 10, kAutoMax = 16u << 20;
 constexpr size_t kAlign = 256;
 constexpr size_t kSliceBytes = 256u << 10;      // unit of work of the copy pool
-constexpr size_t kPoolMinBytes = 512u << 10;    // smaller copy jobs stay on the calling thread
+#ifndef GFDM_HOST_POOL_MIN_BYTES
+#define GFDM_HOST_POOL_MIN_BYTES (512u << 10)
+#endif
+constexpr size_t kPoolMinBytes = GFDM_HOST_POOL_MIN_BYTES;    // smaller copy jobs stay on the calling thread
 constexpr int64_t kMaxLaunchBlocks = 1 << 30;
 constexpr int kTicketStride = 16;               // one 64-byte line per completion ticket
 

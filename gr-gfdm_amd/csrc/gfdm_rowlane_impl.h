@@ -721,8 +721,20 @@ template <int K, int M> struct IcMfma {
 // (ICK_MFMA: at least two waves per SIMD, i.e. at most 256 registers -- below that bound hipcc keeps the MFMA accumulators in ordinary
 // VGPRs, which the dead registers of the FFT phases provide; with the default bound it takes 64 AGPRs ON TOP: 108 + 64 registers = 2 waves
 // per SIMD instead of 120 = 4)
+// GFDM_IC_WAVES_PER_SIMD: since round 4 the rounds need no LDS beyond the tile, so at K=128 M=15 the LDS would let a CU hold ten blocks = five waves per SIMD
+// where the kernel's 98-104 registers hold it at eight.  Asking for five (96 registers, 6-11 of them spilled) measured SLOWER on one box
+// (profiles/r04/ic_waves_per_simd_ab.txt: MF + 2 IC 65.4 against 63.2 us per 8192 blocks, 467 against 457 us per 65 536; ZF + 2 IC 84 against 75 us): the default stays 2.
+#ifndef GFDM_IC_WAVES_PER_SIMD
+#define GFDM_IC_WAVES_PER_SIMD 2
+#endif
+template <int K, int M, int EQ> constexpr int ic_mfma_waves_per_simd()
+{
+    constexpr size_t lds = ((EQ == EQ_PREAMBLE) ? rowgeom::lds_bytes(K, M + 2) + rowgeom::est_bytes(K) : rowgeom::lds_bytes(K, M)) + rowgeom::ic_mfma_edge_bytes(K);
+    constexpr size_t per_cu = (160 * 1024) / ((lds + 511) / 512 * 512) * (size_t)(rowgeom::wg(K) / 64);      // waves the LDS lets a CU hold
+    return per_cu >= 4 * (size_t)GFDM_IC_WAVES_PER_SIMD ? GFDM_IC_WAVES_PER_SIMD : 2;
+}
 template <int K, int M, int L, int MODE, int EQ, int ICK>
-__global__ __launch_bounds__(RowShape<K>::WG, (MODE == RX_IC && ICK == ICK_MFMA) ? 2 : 1) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
+__global__ __launch_bounds__(RowShape<K>::WG, ((MODE == RX_IC && ICK == ICK_MFMA) ? ic_mfma_waves_per_simd<K, M, EQ>() : 1)) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
                                                                 cf* __restrict__ out, const cf* __restrict__ in,
                                                                 const cf* __restrict__ f_eq, int64_t nblocks)
 {

@@ -128,8 +128,8 @@ const char* gfdm_hip_build_id(void);
  *   - ordinary pageable buffers are bounced through pinned staging sets in chunks: the kernel of chunk c works across the link
  *     while the calling thread and a small pool of copy threads move chunk c + 1 in and chunk c - 1 out.  A call that fits one
  *     chunk (<= 1 MiB, e.g. the one block per call of an unchanged GNU Radio wrapper) is copy in, one launch, completion ticket, copy out.
- *   Measured (MI355X box, K=64 M=9, profiles/r04/): pageable 6.7 M blocks/s matched filter, 5.4 M ZF + 2 IC at 65 536 blocks per call;
- *   registered 9.6 M / 6.0 M (88 / 82 GB/s over the link, both directions together); one block per call 13 us either way.
+ *   Measured (MI355X box, K=64 M=9, profiles/r04/bench_default.json): pageable 6.4 M blocks/s matched filter, 4.3 M ZF + 2 IC at 65 536 blocks
+ *   per call; registered 9.6 M / 6.0 M (88 / 82 GB/s over the link, both directions together); one block per call 13-16 us either way.
  * Results do not depend on the route (same kernels, same blocks).  The call returns when `out` is complete.
  *
  * gfdm_hip_register_host: pin a long-lived buffer (a GNU Radio circular buffer, an application's frame store) and map it for every GPU,
