@@ -87,5 +87,5 @@ for c in ("default", "cfg3", "cfg4", "cfg5"):
     rf = j["roofline"]
     w("| %s | %.1f | %s | `%s`: %.2f us -> **%.1f %%** | %.2f us -> %.1f %% | %s |" % (j["config"]["name"], j["value"] / 1e6, ("%.1f" % (j["sustained"]["value"] / 1e6)) if j.get("sustained") else "-",
       rf["kernel"].split(" (")[0], rf["kernel_ms"] * 1e3, 100 * rf["frac"], rf["kernel_ms_pipelined"] * 1e3, 100 * rf["frac_pipelined"],
-      ("%.4f" % (rf["traffic"] / rf["bytes_per_launch"])) if rf.get("traffic") else "null (the bench ran before this directory's PMC summary existed)"))
+      ("%.4f" % (rf["traffic"] / rf["bytes_per_launch"])) if rf.get("traffic") else "null (no PMC row for this kernel and batch)"))
 print("\n".join(out))
