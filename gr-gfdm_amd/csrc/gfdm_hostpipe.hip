@@ -395,8 +395,12 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
     auto done_stream = [&](int64_t c) { return ce_out ? s_out_ : kernel_stream(c); };
     unsigned want[HOST_MAX_DEPTH] = {};
 
+    // bounce copies: the chunks of a large call go to the copy pool as jobs (the bytes of one chunk, in and out, decide); a small call -- the
+    // one-block call of a GNU Radio wrapper -- copies on the spot, no job object, no allocation
+    const bool pooled = helpers > 0 && host_bytes >= kPoolMinBytes;
     std::shared_ptr<CopyJob> job;
     auto job_add = [&](char* dst, const char* src, size_t n) {
+        if (!pooled) { memcpy(dst, src, n); return; }
         if (!job) job = std::make_shared<CopyJob>();
         for (size_t o = 0; o < n; o += kSliceBytes) job->slices.push_back(Slice{ dst + o, src + o, n - o < kSliceBytes ? n - o : kSliceBytes });
     };
@@ -413,14 +417,8 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
     };
     auto run_job = [&]() {
         if (!job) return;
-        size_t bytes = 0;
-        for (const Slice& sl : job->slices) bytes += sl.n;
-        if (helpers > 0 && bytes >= kPoolMinBytes) {
-            const int used = g_pool.run(job, helpers);
-            if (used > st.copy_threads) st.copy_threads = used;
-        } else {
-            for (const Slice& sl : job->slices) memcpy(sl.dst, sl.src, sl.n);
-        }
+        const int used = g_pool.run(job, helpers);
+        if (used > st.copy_threads) st.copy_threads = used;
         job.reset();
     };
 
