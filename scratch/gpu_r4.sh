@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round-4 GPU runner (replaces the one-off scratch/gpu_r3_*.sh launchers):   gpurun -- bash scratch/gpu_r4.sh <task> [tag]
+# (every profiler run sits under its own `timeout`: one collection of the round hung at a profiled process's exit and ran into gpurun's limit)
 #   tests      the whole -m gpu suite + smoke
 #   bench      bench.py default + cfg3 / cfg4 / cfg5 headline lines
 #   events     HIP-event timings of single kernels beside rocprofv3 --kernel-trace on the same box
@@ -10,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 trace() {   # trace <out.csv> <label> <min launches> <run_kernel args...>
   local out=$1 label=$2 minl=$3; shift 3
   rm -rf /tmp/alone/$label
-  rocprofv3 --kernel-trace --output-format csv -d /tmp/alone/$label -o t -- python3 $R/scratch/run_kernel.py "$@" > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/alone/$label -o t -- python3 $R/scratch/run_kernel.py "$@" > /dev/null 2>&1
   python3 $R/scratch/trace_by_shape.py /tmp/alone/$label/t_kernel_trace.csv | grep -E "k_row|k_est|k_generic" | awk -v l=$label -v r=$minl -F'"' '{split($3,a,","); if (a[5]+0 >= r) print l "," "\"" $2 "\"" $3}' >> $out
 }
 case $1 in
@@ -46,7 +47,7 @@ pmc)
               "demod_mf_ic2 8192 128 15 4" "demod_mf_ic2 65536 128 15 4" "demod_zf 8192 256 31 2"; do
     set -- $spec; run=$1_$3_$4_$5_$2; reps=40; [ $2 -ge 65536 ] && reps=12
     for c in FETCH_SIZE WRITE_SIZE; do
-      rocprofv3 --pmc $c --output-format csv -d $O/pmc/$run/$c -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
+      timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc/$run/$c -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
     done
   done
   python3 $R/scratch/pmc_summary.py $O/pmc $id > $O/pmc_hbm_traffic_summary.csv; rm -rf $O/pmc
@@ -57,8 +58,8 @@ sq)     # SQ / LDS counters per wave (two passes of eight counters), with the bu
   for spec in "modulate 4096 64 9 2 1" "demod_mf 4096 64 9 2 1" "demod_mf_ic2 4096 64 9 2 1" "demod_zf_ic2 4096 64 9 2 1" "demod_zf_ic2 65536 64 9 2 1" \
               "demod_mf 8192 128 15 4 1" "demod_mf_ic2 8192 128 15 4 1" "demod_mf_ic2 8192 128 15 4 0" "demod_zf 8192 256 31 2 1"; do
     set -- $spec; run=$1_$3_$4_$5_$2; [ $6 = 0 ] && run=${run}_valu; reps=40; [ $2 -ge 65536 ] && reps=12
-    GFDM_MX=$6 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $O/sq/$run/a -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
-    GFDM_MX=$6 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA --output-format csv -d $O/sq/$run/b -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
+    GFDM_MX=$6 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $O/sq/$run/a -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
+    GFDM_MX=$6 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA --output-format csv -d $O/sq/$run/b -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
   done
   python3 $R/scratch/pmc_summary.py $O/sq $id > $O/pmc_sq_counters_summary.csv; rm -rf $O/sq
   grep -c . $O/pmc_sq_counters_summary.csv ;;
