@@ -598,6 +598,13 @@ int gfdm_hip_get_host_pipeline(int* mode, int64_t* chunk_bytes, int* depth, int*
     gfdm::host_pipeline_get(mode, chunk_bytes, depth, copy_threads, kernel_streams);
     return GFDM_HIP_OK;
 }
+int gfdm_hip_host_call_times(int64_t* ns5)
+{
+    if (!ns5) return fail(GFDM_HIP_EINVAL, "NULL argument");
+    const gfdm::HostCallStats& st = gfdm::host_last_call();
+    ns5[0] = st.ns_setup; ns5[1] = st.ns_copy; ns5[2] = st.ns_launch; ns5[3] = st.ns_post; ns5[4] = st.ns_wait;
+    return GFDM_HIP_OK;
+}
 int gfdm_hip_host_call_stats(int64_t* chunks, int64_t* chunk_blocks, int64_t* staged_bytes, unsigned* direct_mask, int* mode, int* copy_threads)
 {
     const gfdm::HostCallStats& st = gfdm::host_last_call();

@@ -55,6 +55,9 @@ struct HostCallStats {
     int mode = 0;                // 0 kernel on host memory, 1 copy engines
     int depth = 0;               // staging sets in use
     int copy_threads = 0;        // pool threads that helped with the bounce copies
+    // where the calling thread spent the call, nanoseconds: sorting the operands, bounce copies, enqueueing kernels (+ copy commands), posting
+    // tickets, waiting for tickets
+    int64_t ns_setup = 0, ns_copy = 0, ns_launch = 0, ns_post = 0, ns_wait = 0;
 };
 
 class HostPipe {

@@ -5,6 +5,7 @@
 #include "gfdm_plan.h"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -130,6 +131,10 @@ private:
 CopyPool g_pool;
 
 thread_local HostCallStats t_stats;
+
+inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// adds the time since *t to `acc` and restarts *t
+inline void lap(int64_t& acc, int64_t& t) { const int64_t n = now_ns(); acc += n - t; t = n; }
 
 }  // namespace
 
@@ -277,6 +282,7 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
 {
     HostCallStats& st = t_stats;
     st = HostCallStats{};
+    int64_t tl = now_ns();
     if (nops < 1 || nops > HOST_MAX_OPERANDS || nblocks < 0) return api_fail(GFDM_HIP_EINVAL, "bad operand list or negative block count");
     if (nblocks == 0) return GFDM_HIP_OK;
     const int mode = g_mode.load();
@@ -423,17 +429,20 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
     };
 
     int64_t retired = 0;                       // chunks [0, retired) are back in the caller's memory
+    lap(st.ns_setup, tl);
     for (int64_t c = 0; c < nchunks; ++c) {
         const int si = (int)(c % depth);
         Set& s = sets_[si];
         if (c >= depth) {                      // the set is still in use by chunk c - depth: wait for it, take its outputs with this chunk's inputs
             hipError_t e = wait_ticket(done_stream(c - depth), si, want[si]);
             if (e != hipSuccess) { drain(); return api_fail_hip(e, "host call"); }
+            lap(st.ns_wait, tl);
             add_copy_out(c - depth);
             retired = c - depth + 1;
         }
         add_copy_in(c);
         run_job();
+        lap(st.ns_copy, tl);
         const int64_t nb = chunk_nb(c);
         hipStream_t ks = kernel_stream(c);
         void* dev[HOST_MAX_OPERANDS];
@@ -459,16 +468,23 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
                     e = hipMemcpyAsync(direct[i] ? user_ptr(i, c) : s.host + off_host[i], s.dcopy + off_dev[i], chunk_size(i, nb), hipMemcpyDeviceToHost, s_out_);
             if (e != hipSuccess) { drain(); return api_fail_hip(e, "host call: D2H"); }
         }
+        lap(st.ns_launch, tl);
+        // (the ticket kernel's launch costs ~3 us of host time, but it runs in the shadow of the ~8 us the GPU needs from the first launch to a
+        // visible completion: a ticket written by the compute kernel's last workgroup instead was built and measured -- the same 13.5 us per one-block
+        // call, profiles/r04/host_call_breakdown.txt)
         want[si] = ++ticket_next_;
         e = post_ticket(done_stream(c), si, want[si]);
         if (e != hipSuccess) { drain(); return api_fail_hip(e, "host call: ticket"); }
+        lap(st.ns_post, tl);
     }
     for (int64_t c = retired; c < nchunks; ++c) {
         const int si = (int)(c % depth);
         hipError_t e = wait_ticket(done_stream(c), si, want[si]);
         if (e != hipSuccess) { drain(); return api_fail_hip(e, "host call"); }
+        lap(st.ns_wait, tl);
         add_copy_out(c);
         run_job();
+        lap(st.ns_copy, tl);
     }
     return GFDM_HIP_OK;
 }

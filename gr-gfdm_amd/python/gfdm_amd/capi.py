@@ -62,6 +62,7 @@ def lib():
         "gfdm_hip_set_host_pipeline": (i32, [i32, i64, i32, i32, i32]),
         "gfdm_hip_get_host_pipeline": (i32, [vp, vp, vp, vp, vp]),
         "gfdm_hip_host_call_stats": (i32, [vp, vp, vp, vp, vp, vp]),
+        "gfdm_hip_host_call_times": (i32, [vp]),
         "gfdm_hip_modulator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
         "gfdm_hip_modulator_destroy": (i32, [vp]),
         "gfdm_hip_modulator_block_size": (i32, [vp]),
@@ -291,7 +292,10 @@ def host_call_stats():
     ch, cb, sb = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
     dm, md, ct = ctypes.c_uint(0), ctypes.c_int(0), ctypes.c_int(0)
     _check(lib().gfdm_hip_host_call_stats(ctypes.byref(ch), ctypes.byref(cb), ctypes.byref(sb), ctypes.byref(dm), ctypes.byref(md), ctypes.byref(ct)))
-    return dict(chunks=ch.value, chunk_blocks=cb.value, staged_bytes=sb.value, direct_mask=dm.value, mode=md.value, copy_threads=ct.value)
+    ns = (ctypes.c_int64 * 5)()
+    _check(lib().gfdm_hip_host_call_times(ns))
+    return dict(chunks=ch.value, chunk_blocks=cb.value, staged_bytes=sb.value, direct_mask=dm.value, mode=md.value, copy_threads=ct.value,
+                ns=dict(setup=ns[0], copy=ns[1], launch=ns[2], post=ns[3], wait=ns[4]))
 
 
 class registered_host:

@@ -149,6 +149,9 @@ int gfdm_hip_get_host_pipeline(int* mode, int64_t* chunk_bytes, int* depth, int*
 /* What the last *_host call of the calling thread did (any pointer may be NULL): kernel launches, blocks per chunk, bytes bounced,
  * bit i of direct_mask = operand i was used in place (operands in signature order: outputs first, then inputs), route, pool threads used. */
 int gfdm_hip_host_call_stats(int64_t* chunks, int64_t* chunk_blocks, int64_t* staged_bytes, unsigned* direct_mask, int* mode, int* copy_threads);
+/* ... and where the calling thread spent it, nanoseconds: ns5[0] sorting the operands and sizing the staging, [1] bounce copies, [2] enqueueing
+ * the kernels, [3] posting completion tickets, [4] waiting for them.  (A one-block call on the MI355X box: 0.3 / 0.4 / 3.8 / 3.1 / 5.1 us.) */
+int gfdm_hip_host_call_times(int64_t* ns5);
 
 /* ---- modulator_kernel_cc (include/gfdm/modulator_kernel_cc.h:41-51) -------------------- */
 
