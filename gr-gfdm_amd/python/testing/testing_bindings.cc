@@ -10,9 +10,12 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <memory>
+
 #include <gfdm/add_cyclic_prefix_cc.h>
 #include <gfdm/advanced_receiver_kernel_cc.h>
 #include <gfdm/batched_work.h>
+#include <gfdm/host_memory.h>
 #include <gfdm/modulator_kernel_cc.h>
 #include <gfdm/preamble_channel_estimator_cc.h>
 #include <gfdm/receiver_kernel_cc.h>
@@ -29,14 +32,20 @@ typedef py::array_t<cfloat, py::array::c_style | py::array::forcecast> carray;
 namespace {
 
 // work(n) for n in chunks; in / out advance by the returned item count (sync block: consumed == produced)
+// registered: the two streams play the scheduler's long-lived buffers, pinned once with gr::gfdm::host_registration (gfdm/host_memory.h)
 template <class Kernel>
-py::tuple run_sync(Kernel& k, const carray& in_arr, const std::vector<int>& chunks)
+py::tuple run_sync(Kernel& k, const carray& in_arr, const std::vector<int>& chunks, bool registered)
 {
     py::buffer_info in = in_arr.request();
     py::array_t<cfloat> out_arr(in.size);
     cfloat* out = static_cast<cfloat*>(out_arr.request().ptr);
     std::fill(out, out + in.size, cfloat(0.f, 0.f));
     const cfloat* src = static_cast<const cfloat*>(in.ptr);
+    std::unique_ptr<host_registration> reg_in, reg_out;
+    if (registered && in.size > 0) {
+        reg_in = std::make_unique<host_registration>(const_cast<cfloat*>(src), (size_t)in.size * sizeof(cfloat));
+        reg_out = std::make_unique<host_registration>(out, (size_t)in.size * sizeof(cfloat));
+    }
     std::vector<int> returned;
     long pos = 0;
     for (int n : chunks) {
@@ -141,8 +150,8 @@ PYBIND11_MODULE(gfdm_testing, t)
         gfdm_kernel_utils::set_default_device(before);
         return ok;
     });
-    t.def("scheduler_run", &run_sync<modulator_kernel_cc>, py::arg("kernel"), py::arg("stream"), py::arg("noutput_items"));
-    t.def("scheduler_run", &run_sync<receiver_kernel_cc>, py::arg("kernel"), py::arg("stream"), py::arg("noutput_items"));
+    t.def("scheduler_run", &run_sync<modulator_kernel_cc>, py::arg("kernel"), py::arg("stream"), py::arg("noutput_items"), py::arg("registered") = false);
+    t.def("scheduler_run", &run_sync<receiver_kernel_cc>, py::arg("kernel"), py::arg("stream"), py::arg("noutput_items"), py::arg("registered") = false);
     t.def("scheduler_run_equalize", &run_sync_eq, py::arg("kernel"), py::arg("stream"), py::arg("eq_stream"), py::arg("noutput_items"));
     t.def("scheduler_run_transmitter",
           [](transmitter_kernel& k, const carray& in_arr, const std::vector<std::pair<int, int>>& calls, int n_ports) {

@@ -267,3 +267,34 @@ def test_sharded_host_batches_run_their_devices_concurrently(pipeline):
     sb.kernels[2].demodulate = bad
     with pytest.raises(Boom):
         sb.run_global("demodulate", [x], [N])
+
+
+@pytest.mark.parametrize("M,K,L,alpha,nb", [(15, 128, 4, 0.2, 300), (31, 256, 2, 0.1, 70), (5, 32, 2, 0.5, 1000), (21, 37, 2, 0.35, 40), (7, 12, 2, 0.3, 500)])
+def test_baseline_shapes_and_other_kernel_families_through_the_host_path(pipeline, M, K, L, alpha, nb):
+    """BASELINE configs[3] (multi-wavefront blocks, IC rounds on the matrix cores), configs[4] (62 KB tiles), configs[0], a shape of the generic family
+    and a run-time instantiated one: their kernels reading and writing HOST memory (chunked bounce, and in place on registered buffers) give
+    exactly what they give on device memory."""
+    g = pipeline
+    N = M * K
+    taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+    mod, dem = g.Modulator(M, K, L, taps), g.Demodulator(M, K, L, taps)
+    adv = g.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
+    rng = np.random.default_rng(M * K)
+    sym = qpsk(rng, (nb, N))
+    feq = (1.0 + 0.3 * (rng.standard_normal((nb, N)) + 1j * rng.standard_normal((nb, N)))).astype(np.complex64)
+    frames = device_reference(lambda s: mod.modulate(s), sym)
+    refs = (frames, device_reference(lambda x: dem.demodulate(x), frames), device_reference(lambda x, e: dem.demodulate_equalize(x, e), frames, feq),
+            device_reference(lambda x: adv.demodulate(x), frames), device_reference(lambda x, e: adv.demodulate_equalize(x, e), frames, feq))
+    calls = (lambda o: mod.modulate(sym, out=o), lambda o: dem.demodulate(frames, out=o), lambda o: dem.demodulate_equalize(frames, feq, out=o),
+             lambda o: adv.demodulate(frames, out=o), lambda o: adv.demodulate_equalize(frames, feq, out=o))
+    g.set_host_pipeline(0, 7 * 16 * N, 3, 2, 2)                        # seven blocks per chunk (MF) / four (ZF)
+    for call, ref in zip(calls, refs):
+        assert np.array_equal(call(None), ref)
+    assert g.host_call_stats()["chunks"] > 3
+    out = np.empty((nb, N), np.complex64)
+    with g.registered_host(sym, frames, feq, out):
+        g.set_host_pipeline(0, 0, 3, 2, 2)
+        for call, ref in zip(calls, refs):
+            out[:] = 0
+            call(out)
+            assert g.host_call_stats()["staged_bytes"] == 0 and np.array_equal(out, ref)

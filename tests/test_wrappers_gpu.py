@@ -53,6 +53,14 @@ def test_sync_block_work_bodies_with_ragged_scheduler_calls(M, K, L, alpha):
     # identical to the per-block loop of the reference wrapper (same kernels, same inputs)
     per_block = np.stack([dem.demodulate(frames[b * bs:(b + 1) * bs]) for b in range(4)])
     assert np.array_equal(per_block.reshape(-1), out[:4 * bs])
+    # the scheduler's buffers registered once (gr::gfdm::host_registration, gfdm/host_memory.h): the same work() calls run in place on them
+    import gfdm_amd
+    out_reg, ret_reg = T.scheduler_run(dem, frames, chunks[::-1], registered=True)
+    assert ret_reg == ret and np.array_equal(out_reg, out)
+    st = gfdm_amd.host_call_stats()
+    assert st["direct_mask"] == 0b11 and st["staged_bytes"] == 0 and st["chunks"] == 1
+    T.scheduler_run(dem, frames, chunks[::-1])
+    assert gfdm_amd.host_call_stats()["direct_mask"] == 0                       # ... and ordinary memory is bounced again afterwards
     # a run that is not a multiple of the block size: the reference processes the whole blocks and still returns noutput_items
     out2, ret2 = T.scheduler_run(dem, frames[:2 * bs + 7], [2 * bs + 7])
     assert ret2 == [2 * bs + 7] and np.array_equal(out2[:2 * bs], out[:2 * bs]) and not out2[2 * bs:].any()
