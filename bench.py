@@ -443,8 +443,10 @@ def host_batch_paths(cfg, taps, sizes, seconds=0.3, cpu_seconds=1.0, with_cpu=Tr
             if dt > seconds and n >= 3:
                 break
         st = gfdm_amd.host_call_stats()
+        # where the calling thread spent the LAST call (gfdm_hip_host_call_times): sorting operands, bounce copies, kernel launches, ticket launches, waiting
         return {"blocks_per_s": nb * n / dt, "link_GBps": bps * N * nb * n / dt / 1e9, "us_per_call": dt / n * 1e6, "launches_per_call": st["chunks"],
-                "in_place_operands": bin(st["direct_mask"]).count("1"), "copy_threads": st["copy_threads"]}
+                "in_place_operands": bin(st["direct_mask"]).count("1"), "copy_threads": st["copy_threads"],
+                "last_call_us": {k: round(v / 1e3, 2) for k, v in st["ns"].items()}}
 
     res = {}
     for name, (fn, args, bps, _) in calls.items():
