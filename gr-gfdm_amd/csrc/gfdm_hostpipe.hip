@@ -308,6 +308,8 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
         if (a0.type != hipMemoryTypeHost && a0.type != hipMemoryTypeDevice && a0.type != hipMemoryTypeManaged) continue;
         if (hipPointerGetAttributes(&a1, static_cast<char*>(o.host) + extent[i] - 1) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (a1.type != a0.type) continue;                             // only partly registered: bounce it
+        // two registrations side by side need not be contiguous as the GPU sees them: the last byte must sit where the first one says
+        if (a1.devicePointer != static_cast<char*>(a0.devicePointer) + (extent[i] - 1)) continue;
         if (a0.type == hipMemoryTypeDevice && a0.device != cur_dev) return api_fail(GFDM_HIP_EINVAL, "buffer lives in the memory of another GPU");
         if (!a0.devicePointer) continue;
         direct[i] = true;

@@ -298,3 +298,28 @@ def test_baseline_shapes_and_other_kernel_families_through_the_host_path(pipelin
             out[:] = 0
             call(out)
             assert g.host_call_stats()["staged_bytes"] == 0 and np.array_equal(out, ref)
+
+
+def test_a_call_across_two_registrations(pipeline):
+    """two buffers registered one after the other, adjacent in the address space, and a call that runs across the seam: in place only if the GPU
+    sees them contiguously too, bounced otherwise -- the same result either way, never a fault"""
+    g = pipeline
+    M, K, L = 9, 64, 2
+    N = M * K
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    dem = g.Demodulator(M, K, L, taps)
+    nb = 64                                              # 64 blocks x 4608 B = 72 pages: the halves are page aligned
+    x = qpsk(np.random.default_rng(11), (nb, N))
+    ref = dem.demodulate(x)
+    lo, hi = x[:nb // 2], x[nb // 2:]
+    g.register_host(lo)
+    g.register_host(hi)
+    try:
+        out = dem.demodulate(x)
+        st = g.host_call_stats()
+        assert np.array_equal(out, ref) and st["direct_mask"] in (0b00, 0b10)
+        out = dem.demodulate(x[5:nb // 2 - 1])           # inside one registration
+        assert np.array_equal(out, ref[5:nb // 2 - 1]) and g.host_call_stats()["direct_mask"] == 0b10
+    finally:
+        g.unregister_host(lo)
+        g.unregister_host(hi)
