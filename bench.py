@@ -417,13 +417,16 @@ def host_batch_paths(cfg, taps, sizes, seconds=0.3, cpu_seconds=1.0, with_cpu=Tr
     Lb = gfdm_amd.lib()
     nmax = max(sizes)
     bits = np.random.default_rng(0x6FD1).integers(0, 2, (nmax, N, 2), dtype=np.int8)
-    sym = np.empty((nmax, N), np.complex64)
+    # page-aligned arrays: the registered legs pin them (gfdm_hip_register_host takes whole pages)
+    sym = gfdm_amd.aligned_empty((nmax, N))
     sym.real = (2 * bits[:, :, 0] - 1) * np.float32(np.sqrt(0.5))
     sym.imag = (2 * bits[:, :, 1] - 1) * np.float32(np.sqrt(0.5))
     del bits
-    frames = mod.modulate(sym)
-    feq = np.ones((nmax, N), np.complex64)
-    out = np.empty((nmax, N), np.complex64)
+    frames = gfdm_amd.aligned_empty((nmax, N))
+    mod.modulate(sym, out=frames)
+    feq = gfdm_amd.aligned_empty((nmax, N))
+    feq[...] = 1.0
+    out = gfdm_amd.aligned_empty((nmax, N))
     vp = lambda x: None if x is None else ctypes.c_void_p(x.ctypes.data)
     calls = {
         "host_batch_modulate": (Lb.gfdm_hip_modulator_work_host, [mod._h, vp(out), vp(sym)], 16, ("mod", False, 0)),

@@ -20,7 +20,8 @@ namespace gfdm {
 class GFDM_API host_registration
 {
 public:
-    /* pins [ptr, ptr + bytes) and maps it for every GPU (~16 us per MiB); throws std::runtime_error when the driver cannot (the memory then
+    /* pins [ptr, ptr + bytes) -- whole pages the caller owns: start and size multiples of the page size, as mmap'ed scheduler buffers are -- and maps
+     * it for every GPU (~16 us per MiB); throws std::runtime_error when the range is not whole pages or the driver cannot pin it (the memory then
      * simply stays on the bounce path -- catching the exception is a valid way to run) */
     host_registration(void* ptr, std::size_t bytes);
     ~host_registration();                                   /* unregisters; the memory itself is the caller's */

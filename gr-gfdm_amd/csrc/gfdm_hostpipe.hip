@@ -7,9 +7,11 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <unistd.h>
 
 namespace gfdm {
 
@@ -132,6 +134,18 @@ CopyPool g_pool;
 
 thread_local HostCallStats t_stats;
 
+// the ranges pinned through gfdm_hip_register_host (whole pages each): a host call uses an operand in place only if ONE of them holds all of it
+std::mutex g_reg_mu;
+std::vector<std::pair<const char*, size_t>> g_registered;
+bool registry_contains(const void* p, size_t bytes)
+{
+    const char* c = static_cast<const char*>(p);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    for (const auto& r : g_registered)
+        if (c >= r.first && c + bytes <= r.first + r.second) return true;
+    return false;
+}
+
 inline int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // adds the time since *t to `acc` and restarts *t
 inline void lap(int64_t& acc, int64_t& t) { const int64_t n = now_ns(); acc += n - t; t = n; }
@@ -165,16 +179,35 @@ void host_copy_pool_quiesce() { g_pool.quiesce(); }
 int host_register(void* p, size_t bytes)
 {
     if (!p || bytes == 0) return api_fail(GFDM_HIP_EINVAL, "register_host: NULL pointer or zero size");
+    // Whole pages only.  Pinning works on pages: a range that begins or ends inside a page drags its neighbours in that page along, and when such a
+    // page is unpinned again under a neighbour the runtime also pins on the fly (a pageable hipMemcpy of some other object in that page), the GPU
+    // later faults on it -- seen with small heap arrays in scratch/fuzz_host_path.py (profiles/r04/host_path_fuzz.txt).  A scheduler's buffers
+    // (mmap'ed, page-granular) and anything from aligned_alloc / posix_memalign with a page-multiple size qualify.
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    if (reinterpret_cast<uintptr_t>(p) % page != 0 || bytes % page != 0) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "register_host: the range must be whole pages the caller owns (start and size multiples of %zu bytes)", page);
+        return api_fail(GFDM_HIP_EINVAL, buf);
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return api_fail(GFDM_HIP_ENODEV, "no HIP device available");
     hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
     if (e != hipSuccess) { (void)hipGetLastError(); return api_fail_hip(e, "hipHostRegister"); }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_registered.emplace_back(static_cast<const char*>(p), bytes);
     return GFDM_HIP_OK;
 }
 
 int host_unregister(void* p)
 {
     if (!p) return api_fail(GFDM_HIP_EINVAL, "unregister_host: NULL pointer");
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        bool found = false;
+        for (size_t i = 0; i < g_registered.size(); ++i)
+            if (g_registered[i].first == static_cast<const char*>(p)) { g_registered.erase(g_registered.begin() + (long)i); found = true; break; }
+        if (!found) return api_fail(GFDM_HIP_EINVAL, "unregister_host: this pointer was not registered with gfdm_hip_register_host");
+    }
     hipError_t e = hipHostUnregister(p);
     if (e != hipSuccess) { (void)hipGetLastError(); return api_fail_hip(e, "hipHostUnregister"); }
     return GFDM_HIP_OK;
@@ -310,6 +343,18 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
         if (a1.type != a0.type) continue;                             // only partly registered: bounce it
         // two registrations side by side need not be contiguous as the GPU sees them: the last byte must sit where the first one says
         if (a1.devicePointer != static_cast<char*>(a0.devicePointer) + (extent[i] - 1)) continue;
+        // ... and the WHOLE range must lie inside ONE registration / allocation: small heap buffers share pages with their neighbours, so a buffer
+        // that was never registered can begin in the last page of one registered neighbour and end in the first page of another -- both ends
+        // look registered, the pages in between are not, and the kernel would fault on them (found by scratch/fuzz_host_path.py)
+        // Ranges registered through gfdm_hip_register_host are known exactly; for memory pinned or allocated by somebody else (hipHostMalloc, a device
+        // allocation) the runtime is asked for the allocation around the pointer, and where it cannot tell the operand is bounced.
+        if (!registry_contains(o.host, extent[i])) {
+            hipDeviceptr_t rbase = nullptr;
+            size_t rsize = 0;
+            if (hipMemGetAddressRange(&rbase, &rsize, a0.devicePointer) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (static_cast<char*>(a0.devicePointer) < static_cast<char*>(rbase) ||
+                static_cast<char*>(a0.devicePointer) + extent[i] > static_cast<char*>(rbase) + rsize) continue;
+        }
         if (a0.type == hipMemoryTypeDevice && a0.device != cur_dev) return api_fail(GFDM_HIP_EINVAL, "buffer lives in the memory of another GPU");
         if (!a0.devicePointer) continue;
         direct[i] = true;

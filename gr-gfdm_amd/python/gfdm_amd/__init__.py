@@ -6,4 +6,4 @@
 from . import filters  # noqa: F401
 from .capi import (AdvancedReceiver, ChannelEstimator, CyclicPrefixer, Demodulator, GfdmHipError, Modulator, ResourceMapper, Transmitter, exported_symbols,  # noqa: F401
                    JIT_AUTO, JIT_BACKGROUND, JIT_IN_CONSTRUCTOR, JIT_OFF, generic_family_for_testing, lib, precompile, quiesce, set_dft_matrix_cores, set_ic_matrix_cores, set_jit,
-                   HOST_COPY_ENGINES, HOST_ZERO_COPY, build_id, get_host_pipeline, host_call_stats, register_host, registered_host, set_host_pipeline, unregister_host)
+                   HOST_COPY_ENGINES, HOST_ZERO_COPY, aligned_copy, aligned_empty, build_id, get_host_pipeline, host_call_stats, register_host, registered_host, set_host_pipeline, unregister_host)

@@ -323,8 +323,30 @@ class registered_host:
         return False
 
 
+PAGE = 4096
+
+
+def aligned_empty(shape, dtype=np.complex64):
+    """An uninitialised C-contiguous array that starts on a page boundary and owns its pages to the end of the last one: what register_host takes
+    (gfdm_hip_register_host pins whole pages).  The backing buffer stays alive with the array."""
+    import mmap
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    size = max(PAGE, -(-n // PAGE) * PAGE)
+    buf = mmap.mmap(-1, size)                          # anonymous, page aligned, page granular
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def aligned_copy(array):
+    out = aligned_empty(array.shape, array.dtype)
+    out[...] = array
+    return out
+
+
 def register_host(array):
-    _check(lib().gfdm_hip_register_host(array.ctypes.data, array.nbytes))
+    """gfdm_hip_register_host on an array from aligned_empty / aligned_copy (or any array that starts on a page boundary and owns the rest of its last page)."""
+    if array.ctypes.data % PAGE:
+        raise ValueError("register_host: the array must start on a page boundary (gfdm_amd.aligned_empty / aligned_copy)")
+    _check(lib().gfdm_hip_register_host(array.ctypes.data, -(-array.nbytes // PAGE) * PAGE))
 
 
 def unregister_host(array):

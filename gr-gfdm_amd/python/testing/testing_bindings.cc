@@ -10,6 +10,8 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <memory>
 
 #include <gfdm/add_cyclic_prefix_cc.h>
@@ -41,10 +43,22 @@ py::tuple run_sync(Kernel& k, const carray& in_arr, const std::vector<int>& chun
     cfloat* out = static_cast<cfloat*>(out_arr.request().ptr);
     std::fill(out, out + in.size, cfloat(0.f, 0.f));
     const cfloat* src = static_cast<const cfloat*>(in.ptr);
+    // the scheduler's buffers: whole pages (as GNU Radio's mmap'ed circular buffers are), registered for the lifetime of the run
     std::unique_ptr<host_registration> reg_in, reg_out;
+    struct Free { void operator()(void* p) const { free(p); } };
+    std::unique_ptr<void, Free> ring_in, ring_out;
+    cfloat* user_out = out;
     if (registered && in.size > 0) {
-        reg_in = std::make_unique<host_registration>(const_cast<cfloat*>(src), (size_t)in.size * sizeof(cfloat));
-        reg_out = std::make_unique<host_registration>(out, (size_t)in.size * sizeof(cfloat));
+        const size_t bytes = ((size_t)in.size * sizeof(cfloat) + 4095) / 4096 * 4096;
+        ring_in.reset(aligned_alloc(4096, bytes));
+        ring_out.reset(aligned_alloc(4096, bytes));
+        if (!ring_in || !ring_out) throw std::bad_alloc();
+        memcpy(ring_in.get(), src, (size_t)in.size * sizeof(cfloat));
+        memset(ring_out.get(), 0, bytes);
+        reg_in = std::make_unique<host_registration>(ring_in.get(), bytes);
+        reg_out = std::make_unique<host_registration>(ring_out.get(), bytes);
+        src = static_cast<const cfloat*>(ring_in.get());
+        out = static_cast<cfloat*>(ring_out.get());
     }
     std::vector<int> returned;
     long pos = 0;
@@ -54,6 +68,7 @@ py::tuple run_sync(Kernel& k, const carray& in_arr, const std::vector<int>& chun
         returned.push_back(r);
         pos += r;
     }
+    if (out != user_out) memcpy(user_out, out, (size_t)in.size * sizeof(cfloat));
     return py::make_tuple(out_arr, returned);
 }
 

@@ -133,7 +133,9 @@ const char* gfdm_hip_build_id(void);
  * Results do not depend on the route (same kernels, same blocks).  The call returns when `out` is complete.
  *
  * gfdm_hip_register_host: pin a long-lived buffer (a GNU Radio circular buffer, an application's frame store) and map it for every GPU,
- * ~16 us per MiB once; later *_host calls on any part of it skip the bounce.  Unregister before the memory is freed. */
+ * ~16 us per MiB once; later *_host calls on any part of it skip the bounce.  The range must be WHOLE PAGES the caller owns -- start and size
+ * multiples of the page size (mmap'ed buffers, aligned_alloc / posix_memalign with a page-multiple size), GFDM_HIP_EINVAL otherwise: pinning is
+ * per page, and a page shared with other objects must not be pinned and unpinned under them.  Unregister before the memory is freed. */
 int gfdm_hip_register_host(void* ptr, size_t bytes);
 int gfdm_hip_unregister_host(void* ptr);
 /* Process-wide tuning of the bounce (negative = leave unchanged).  mode = how the bytes cross the link: 0 (default) under the kernels' own

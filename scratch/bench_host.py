@@ -38,10 +38,10 @@ def main():
     sizes = [int(s) for s in a.sizes.split(",")]
     nmax = max(sizes)
     rng = np.random.default_rng(0)
-    sym = ((1 - 2 * rng.integers(0, 2, (nmax, N))) + 1j * (1 - 2 * rng.integers(0, 2, (nmax, N)))).astype(np.complex64) / np.float32(np.sqrt(2))
-    frames = mod.modulate(sym)
-    feq = np.ones((nmax, N), np.complex64)
-    out = np.empty((nmax, N), np.complex64)
+    sym = gfdm_amd.aligned_copy(((1 - 2 * rng.integers(0, 2, (nmax, N))) + 1j * (1 - 2 * rng.integers(0, 2, (nmax, N)))).astype(np.complex64) / np.float32(np.sqrt(2)))
+    frames = gfdm_amd.aligned_copy(mod.modulate(sym))
+    feq = gfdm_amd.aligned_empty((nmax, N)); feq[...] = 1.0
+    out = gfdm_amd.aligned_empty((nmax, N))
     paths = {
         "modulate": (Lb.gfdm_hip_modulator_work_host, mod._h, (sym,), 16),
         "demod_mf": (Lb.gfdm_hip_receiver_demodulate_host, dem._h, (frames, None), 16),

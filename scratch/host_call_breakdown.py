@@ -8,8 +8,8 @@ from gfdm_amd.filters import get_frequency_domain_filter
 M, K, L = 9, 64, 2
 N = M * K
 dem = gfdm_amd.Demodulator(M, K, L, get_frequency_domain_filter("rrc", 0.2, M, K, L))
-x = (np.random.default_rng(0).standard_normal((256, N)) + 0j).astype(np.complex64)
-out = np.empty_like(x)
+x = gfdm_amd.aligned_copy((np.random.default_rng(0).standard_normal((256, N)) + 0j).astype(np.complex64))
+out = gfdm_amd.aligned_empty(x.shape)
 fn = gfdm_amd.lib().gfdm_hip_receiver_demodulate_host
 tm = gfdm_amd.lib().gfdm_hip_host_call_times
 def run(nb, reps=2000):

@@ -3,6 +3,7 @@
  * modulator and the receiver (error codes, determinism of the arithmetic under scaling), and a run of blocks goes through buffers
  * registered once with gfdm_hip_register_host -- what a GNU Radio block does with its long-lived circular buffers -- which the host
  * calls then use in place (gfdm_hip_host_call_stats), with the results of the bounced call. */
+#define _POSIX_C_SOURCE 200112L      /* posix_memalign: page-aligned buffers for gfdm_hip_register_host */
 #include <gfdm_hip.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -46,17 +47,20 @@ int main(void)
     }
     {   /* a scheduler's buffers: allocated once, registered once, any run of blocks inside them per call */
         enum { NB = 700 };
-        const size_t bytes = (size_t)NB * N * 2 * sizeof(float);
-        float* ring_in = (float*)malloc(bytes);
-        float* ring_out = (float*)malloc(bytes);
+        const size_t bytes = (size_t)NB * N * 2 * sizeof(float), pages = (bytes + 4095) / 4096 * 4096;    /* registration takes whole pages */
+        void *ring_in_v = NULL, *ring_out_v = NULL;
+        float *ring_in, *ring_out;
         float* plain_out = (float*)malloc(bytes);
         int64_t chunks = 0, staged = 0;
         unsigned direct = 0;
-        if (!ring_in || !ring_out || !plain_out) return 30;
+        if (posix_memalign(&ring_in_v, 4096, pages) != 0 || posix_memalign(&ring_out_v, 4096, pages) != 0 || !plain_out) return 30;
+        ring_in = (float*)ring_in_v;
+        ring_out = (float*)ring_out_v;
         for (i = 0; i < NB * N * 2; ++i) ring_in[i] = mid[i % (2 * N)] * (float)(1 + i % 5);
         if (gfdm_hip_receiver_demodulate_host(rx, plain_out, ring_in, NULL, NB) != GFDM_HIP_OK) return 31;          /* pageable: bounced */
         if (gfdm_hip_host_call_stats(&chunks, NULL, &staged, &direct, NULL, NULL) != GFDM_HIP_OK || direct != 0 || staged != (int64_t)(2 * bytes)) return 32;
-        if (gfdm_hip_register_host(ring_in, bytes) != GFDM_HIP_OK || gfdm_hip_register_host(ring_out, bytes) != GFDM_HIP_OK) { printf("register: %s\n", gfdm_hip_last_error()); return 33; }
+        if (gfdm_hip_register_host(plain_out + 1, 4096) != GFDM_HIP_EINVAL) return 39;                             /* not whole pages: refused */
+        if (gfdm_hip_register_host(ring_in, pages) != GFDM_HIP_OK || gfdm_hip_register_host(ring_out, pages) != GFDM_HIP_OK) { printf("register: %s\n", gfdm_hip_last_error()); return 33; }
         if (gfdm_hip_receiver_demodulate_host(rx, ring_out + 2 * N * 3, ring_in + 2 * N * 3, NULL, NB - 3) != GFDM_HIP_OK) return 34;   /* a run inside the buffers */
         if (gfdm_hip_host_call_stats(&chunks, NULL, &staged, &direct, NULL, NULL) != GFDM_HIP_OK || direct != 3u || staged != 0 || chunks != 1) return 35;
         if (memcmp(ring_out + 2 * N * 3, plain_out + 2 * N * 3, bytes - (size_t)3 * N * 2 * sizeof(float)) != 0) return 36;

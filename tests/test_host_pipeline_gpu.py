@@ -95,11 +95,15 @@ def test_registered_buffers_are_used_in_place(pipeline):
     rng = np.random.default_rng(5)
     nb = 300
     sym = qpsk(rng, (nb, N))
-    frames = mod.modulate(sym)
-    feq = (1.0 + 0.3 * (rng.standard_normal((nb, N)) + 1j * rng.standard_normal((nb, N)))).astype(np.complex64)
-    ref = adv.demodulate_equalize(frames, feq)                        # bounced (pageable numpy memory)
+    # registration takes whole pages the caller owns: page-aligned arrays (gfdm_amd.aligned_empty / aligned_copy)
+    frames = g.aligned_copy(mod.modulate(sym))
+    feq = g.aligned_copy((1.0 + 0.3 * (rng.standard_normal((nb, N)) + 1j * rng.standard_normal((nb, N)))).astype(np.complex64))
+    ref = adv.demodulate_equalize(frames, feq)                        # bounced (not registered yet)
     assert g.host_call_stats()["direct_mask"] == 0 and g.host_call_stats()["chunks"] >= 2
-    out = np.empty_like(ref)
+    out = g.aligned_empty(ref.shape)
+    with pytest.raises(ValueError):
+        g.register_host(np.empty(10000, np.complex64)[3:])           # not on a page boundary: refused (a page shared with other objects must not be pinned)
+    assert g.lib().gfdm_hip_register_host(frames.ctypes.data, 1000) == g.capi.EINVAL      # ... and so is a size that is not whole pages
     with g.registered_host(out, frames, feq):
         res = adv.demodulate_equalize(frames, feq, out=out)
         st = g.host_call_stats()
@@ -119,7 +123,7 @@ def test_registered_buffers_are_used_in_place(pipeline):
         assert g.host_call_stats()["direct_mask"] == 0b111
         assert np.array_equal(out[7:130], ref[7:130]) and not out[:7].any() and not out[130:].any()
         # in place (out is in): the reference's generic_work copies its input first, so callers may rely on it -- the output is bounced
-        buf = frames.copy()
+        buf = g.aligned_copy(frames)
         g.register_host(buf)
         try:
             mf = g.Demodulator(M, K, L, taps)
@@ -151,7 +155,8 @@ def test_65537_blocks_with_the_automatic_chunk_plan(pipeline):
     nb = 65537
     rng = np.random.default_rng(6)
     sym = qpsk(rng, (nb, N))
-    frames = mod.modulate(sym)
+    frames = g.aligned_empty((nb, N))
+    mod.modulate(sym, out=frames)
     st = g.host_call_stats()
     assert st["chunks"] > 8 and st["direct_mask"] == 0 and st["copy_threads"] >= 1
     assert np.array_equal(frames, device_reference(lambda s: mod.modulate(s), sym))
@@ -159,7 +164,7 @@ def test_65537_blocks_with_the_automatic_chunk_plan(pipeline):
     assert np.array_equal(out, device_reference(lambda x: dem.demodulate(x), frames))
     # size-independent property at the full size: the matched-filter receiver returns the symbols up to the filter's self-interference
     assert np.max(np.abs(out[-1] - sym[-1])) < 0.6 and np.array_equal(np.sign(out.real[::4097]), np.sign(sym.real[::4097]))
-    reg = np.empty_like(out)
+    reg = g.aligned_empty(out.shape)
     with g.registered_host(frames, reg):
         dem.demodulate(frames, out=reg)
         assert g.host_call_stats()["chunks"] == 1 and g.host_call_stats()["staged_bytes"] == 0
@@ -280,9 +285,9 @@ def test_baseline_shapes_and_other_kernel_families_through_the_host_path(pipelin
     mod, dem = g.Modulator(M, K, L, taps), g.Demodulator(M, K, L, taps)
     adv = g.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points())
     rng = np.random.default_rng(M * K)
-    sym = qpsk(rng, (nb, N))
-    feq = (1.0 + 0.3 * (rng.standard_normal((nb, N)) + 1j * rng.standard_normal((nb, N)))).astype(np.complex64)
-    frames = device_reference(lambda s: mod.modulate(s), sym)
+    sym = g.aligned_copy(qpsk(rng, (nb, N)))
+    feq = g.aligned_copy((1.0 + 0.3 * (rng.standard_normal((nb, N)) + 1j * rng.standard_normal((nb, N)))).astype(np.complex64))
+    frames = g.aligned_copy(device_reference(lambda s: mod.modulate(s), sym))
     refs = (frames, device_reference(lambda x: dem.demodulate(x), frames), device_reference(lambda x, e: dem.demodulate_equalize(x, e), frames, feq),
             device_reference(lambda x: adv.demodulate(x), frames), device_reference(lambda x, e: adv.demodulate_equalize(x, e), frames, feq))
     calls = (lambda o: mod.modulate(sym, out=o), lambda o: dem.demodulate(frames, out=o), lambda o: dem.demodulate_equalize(frames, feq, out=o),
@@ -291,7 +296,7 @@ def test_baseline_shapes_and_other_kernel_families_through_the_host_path(pipelin
     for call, ref in zip(calls, refs):
         assert np.array_equal(call(None), ref)
     assert g.host_call_stats()["chunks"] > 3
-    out = np.empty((nb, N), np.complex64)
+    out = g.aligned_empty((nb, N))
     with g.registered_host(sym, frames, feq, out):
         g.set_host_pipeline(0, 0, 3, 2, 2)
         for call, ref in zip(calls, refs):
@@ -309,7 +314,7 @@ def test_a_call_across_two_registrations(pipeline):
     taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
     dem = g.Demodulator(M, K, L, taps)
     nb = 64                                              # 64 blocks x 4608 B = 72 pages: the halves are page aligned
-    x = qpsk(np.random.default_rng(11), (nb, N))
+    x = g.aligned_copy(qpsk(np.random.default_rng(11), (nb, N)))
     ref = dem.demodulate(x)
     lo, hi = x[:nb // 2], x[nb // 2:]
     g.register_host(lo)
