@@ -56,7 +56,7 @@ a = s.index('   | blocks per `work()` call | 1 | 16 | 256 | 4096 | 65 536 |'); b
 f = lambda k, kind, n: P[k][kind][n]['blocks_per_s'] / 1e6
 t = ['   | blocks per `work()` call | 1 | 16 | 256 | 4096 | 65 536 |', '   |---|---|---|---|---|---|']
 t.append('   | MF demodulate, pageable buffers (bounced in chunks) | %.3f | %.2f | %.1f | %.1f | %.1f |' % tuple(f('host_batch_demod_mf', 'pageable', n) for n in ('1', '16', '256', '4096', '65536')))
-t.append('   | MF demodulate, buffers registered once (used in place) | %.3f | %.2f | %.1f | %.1f | %.1f (88 GB/s over the link, both directions) |' % tuple(f('host_batch_demod_mf', 'registered', n) for n in ('1', '16', '256', '4096', '65536')))
+t.append('   | MF demodulate, buffers registered once (used in place) | %.3f | %.2f | %.1f | %.1f | %.1f (%.0f GB/s over the link, both directions) |' % (tuple(f('host_batch_demod_mf', 'registered', n) for n in ('1', '16', '256', '4096', '65536')) + (P['host_batch_demod_mf']['registered']['65536']['link_GBps'],)))
 t.append('   | ZF + 2 IC (three pointers per block), pageable / registered | %s |' % ' | '.join('%.2g / %.2g' % (f('host_batch_zf_ic2', 'pageable', n), f('host_batch_zf_ic2', 'registered', n)) for n in ('1', '16', '256', '4096', '65536')))
 s = s[:a] + '\n'.join(t) + '\n\n' + s[b:]
 open(p, 'w').write(s)
@@ -113,12 +113,12 @@ s = open(p).read()
 a = s.index('**With host buffers**'); b = s.index('Shapes outside the compiled list are instantiated at run time')
 new = '''**With host buffers** -- what gr-gfdm's GNU Radio wrappers hand over -- the `*_host` entry points run a chunked pipeline (DESIGN.md §16): pageable buffers are bounced through
 pinned staging sets while the kernels work across the PCIe link, buffers registered once with `gfdm_hip_register_host` are used in place.  K=64 M=9 MF demodulation:
-**%.1f M blocks/s** from pageable memory and **%.1f M blocks/s** (88 GB/s over the link, both directions) from registered memory at 65 536 blocks per call, %.1f / %.1f M at 4096,
+**%.1f M blocks/s** from pageable memory and **%.1f M blocks/s** (%.0f GB/s over the link, both directions) from registered memory at 65 536 blocks per call, %.1f / %.1f M at 4096,
 %.2f / %.2f M at 16; ZF + 2 IC %.1f / %.1f M -- against %.2f M blocks/s for the plain-C port of the reference algorithm on one thread (how a GNU Radio block runs it) and %.1f M
 on the 16 CPUs the box's cgroup grants (the pool's boxes: 5.3-6.7 M pageable).  One block per call costs 13-16 us (launch + completion latency: 3.8 us in the launch, ~8 us until
 the GPU reports back), more than the CPU's 4.2 us: the GPU pays off through the batched `work()` bodies of `gfdm/batched_work.h`.
 
-''' % (f('host_batch_demod_mf', 'pageable', '65536'), f('host_batch_demod_mf', 'registered', '65536'), f('host_batch_demod_mf', 'pageable', '4096'), f('host_batch_demod_mf', 'registered', '4096'),
+''' % (f('host_batch_demod_mf', 'pageable', '65536'), f('host_batch_demod_mf', 'registered', '65536'), P['host_batch_demod_mf']['registered']['65536']['link_GBps'], f('host_batch_demod_mf', 'pageable', '4096'), f('host_batch_demod_mf', 'registered', '4096'),
        f('host_batch_demod_mf', 'pageable', '16'), f('host_batch_demod_mf', 'registered', '16'), f('host_batch_zf_ic2', 'pageable', '65536'), f('host_batch_zf_ic2', 'registered', '65536'),
        P['host_batch_demod_mf']['cpu_port']['single_thread_blocks_per_s'] / 1e6, P['host_batch_demod_mf']['cpu_port']['blocks_per_s'] / 1e6)
 s = s[:a] + new + s[b:]
