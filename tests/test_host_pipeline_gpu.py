@@ -328,3 +328,26 @@ def test_a_call_across_two_registrations(pipeline):
     finally:
         g.unregister_host(lo)
         g.unregister_host(hi)
+
+
+def test_memory_pinned_or_owned_by_somebody_else(pipeline):
+    """hipHostMalloc'ed memory (a torch pinned tensor) and device memory handed to a *_host entry point are used in place as well: the runtime vouches for the
+    whole allocation (hipMemGetAddressRange), no registration call is needed."""
+    import ctypes
+    import torch
+    g = pipeline
+    M, K, L = 9, 64, 2
+    N, nb = M * K, 300
+    dem = g.Demodulator(M, K, L, get_frequency_domain_filter("rrc", 0.2, M, K, L))
+    xp, op = torch.empty(nb, N, dtype=torch.complex64).pin_memory(), torch.empty(nb, N, dtype=torch.complex64).pin_memory()
+    x, o = xp.numpy(), op.numpy()
+    x[...] = qpsk(np.random.default_rng(12), (nb, N))
+    ref = dem.demodulate(np.array(x))                                   # a pageable copy: bounced
+    assert g.host_call_stats()["direct_mask"] == 0
+    dem.demodulate(x, out=o)
+    st = g.host_call_stats()
+    assert st["direct_mask"] == 0b11 and st["staged_bytes"] == 0 and np.array_equal(o, ref)
+    xd = xp.cuda()
+    od = torch.empty_like(xd)
+    assert g.lib().gfdm_hip_receiver_demodulate_host(dem._h, ctypes.c_void_p(od.data_ptr()), ctypes.c_void_p(xd.data_ptr()), None, ctypes.c_int64(nb)) == 0
+    assert g.host_call_stats()["direct_mask"] == 0b11 and np.array_equal(od.cpu().numpy(), ref)
