@@ -605,6 +605,7 @@ int gfdm_hip_host_call_times(int64_t* ns5)
     ns5[0] = st.ns_setup; ns5[1] = st.ns_copy; ns5[2] = st.ns_launch; ns5[3] = st.ns_post; ns5[4] = st.ns_wait;
     return GFDM_HIP_OK;
 }
+int gfdm_hip_set_host_streaming_copies_for_testing(int enable) { return gfdm::host_streaming_copies(enable); }
 int gfdm_hip_host_call_stats(int64_t* chunks, int64_t* chunk_blocks, int64_t* staged_bytes, unsigned* direct_mask, int* mode, int* copy_threads)
 {
     const gfdm::HostCallStats& st = gfdm::host_last_call();

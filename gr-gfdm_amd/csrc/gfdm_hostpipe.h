@@ -98,6 +98,7 @@ private:
 int host_pipeline_set(int mode, int64_t chunk_bytes, int depth, int copy_threads, int kernel_streams);
 void host_pipeline_get(int* mode, int64_t* chunk_bytes, int* depth, int* copy_threads, int* kernel_streams);
 HostCallStats& host_last_call();           // thread-local
+int host_streaming_copies(int enable);     // A/B switch: 0 = plain memcpy for the bounce copies; returns the previous setting
 void host_copy_pool_quiesce();             // stop the copy threads (library exit path, gfdm_hip_quiesce)
 int host_register(void* p, size_t bytes);
 int host_unregister(void* p);

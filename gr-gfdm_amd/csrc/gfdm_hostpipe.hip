@@ -12,6 +12,7 @@
 #include <mutex>
 #include <thread>
 #include <unistd.h>
+#include <immintrin.h>
 
 namespace gfdm {
 
@@ -46,10 +47,53 @@ __global__ void k_host_ticket(volatile unsigned* ticket, unsigned value)
     *ticket = value;
 }
 
+// ---- bounce copies -------------------------------------------------------------------------------------------------------------------
+// A bounce copy writes memory the CPU will not read again soon (the staging set is read by the GPU, the caller's output by whoever comes next),
+// so large copies use non-temporal stores: no read-for-ownership of the destination lines, two memory operations per byte instead of three.
+// glibc's memcpy does the same, but only above a threshold of several MiB; the pool cuts copies into 256 KiB slices, far below it
+// (profiles/r04/host_copy_streaming_stores.txt: one copy thread 31 -> 42 GB/s, four 69 -> 105 GB/s, a 32 768-block call 3.2 -> 4.4 / 6.7 -> 7.2 M blocks/s).
+// Only for calls that stage kStreamCallBytes or more in all: from there on the streaming form measured faster or equal at every size
+// (profiles/r04/host_mid_size_calls.txt: 512 blocks 194-218 -> 137-156 us, 1024 blocks 224-261 -> 194-209 us, 256 blocks equal); smaller calls keep
+// memcpy, which leaves their few hundred KiB of results in cache for whoever reads them next.
+constexpr size_t kStreamMinBytes = 32u << 10;
+#ifndef GFDM_HOST_STREAM_CALL_BYTES
+#define GFDM_HOST_STREAM_CALL_BYTES (2u << 20)
+#endif
+constexpr size_t kStreamCallBytes = GFDM_HOST_STREAM_CALL_BYTES;
+
+__attribute__((target("avx2"))) void copy_streaming_avx2(char* d, const char* s, size_t n)
+{
+    const size_t head = (32 - (reinterpret_cast<uintptr_t>(d) & 31)) & 31;       // stores must be 32-byte aligned
+    if (head) { memcpy(d, s, head); d += head; s += head; n -= head; }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 64));
+        const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(d + i + 96), e);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(d + i, s + i, n - i);
+}
+
+const bool g_have_avx2 = __builtin_cpu_supports("avx2");
+std::atomic<int> g_streaming_copies{ 1 };       // 0: plain memcpy everywhere (A/B)
+
+inline void bounce_copy(char* d, const char* s, size_t n, bool streaming)
+{
+    if (streaming && n >= kStreamMinBytes) copy_streaming_avx2(d, s, n);
+    else memcpy(d, s, n);
+}
+
 // ---- copy pool: the bounce copies of one chunk, cut into slices, shared between the calling thread and a few pool threads -------------
 struct Slice { char* dst; const char* src; size_t n; };
 struct CopyJob {
     std::vector<Slice> slices;
+    bool streaming = false;
     std::atomic<size_t> next{ 0 }, done{ 0 };
     void work()
     {
@@ -57,7 +101,7 @@ struct CopyJob {
         for (;;) {
             const size_t i = next.fetch_add(1, std::memory_order_relaxed);
             if (i >= n) return;
-            memcpy(slices[i].dst, slices[i].src, slices[i].n);
+            bounce_copy(slices[i].dst, slices[i].src, slices[i].n, streaming);
             done.fetch_add(1, std::memory_order_release);
         }
     }
@@ -174,6 +218,7 @@ void host_pipeline_get(int* mode, int64_t* chunk_bytes, int* depth, int* copy_th
 }
 
 HostCallStats& host_last_call() { return t_stats; }
+int host_streaming_copies(int enable) { return g_streaming_copies.exchange(enable ? 1 : 0); }
 void host_copy_pool_quiesce() { g_pool.quiesce(); }
 
 int host_register(void* p, size_t bytes)
@@ -451,10 +496,11 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
     // bounce copies: the chunks of a large call go to the copy pool as jobs (the bytes of one chunk, in and out, decide); a small call -- the
     // one-block call of a GNU Radio wrapper -- copies on the spot, no job object, no allocation
     const bool pooled = helpers > 0 && host_bytes >= kPoolMinBytes;
+    const bool streaming = total_staged >= kStreamCallBytes && g_have_avx2 && g_streaming_copies.load(std::memory_order_relaxed) != 0;
     std::shared_ptr<CopyJob> job;
     auto job_add = [&](char* dst, const char* src, size_t n) {
-        if (!pooled) { memcpy(dst, src, n); return; }
-        if (!job) job = std::make_shared<CopyJob>();
+        if (!pooled) { bounce_copy(dst, src, n, streaming); return; }
+        if (!job) { job = std::make_shared<CopyJob>(); job->streaming = streaming; }
         for (size_t o = 0; o < n; o += kSliceBytes) job->slices.push_back(Slice{ dst + o, src + o, n - o < kSliceBytes ? n - o : kSliceBytes });
     };
     auto user_ptr = [&](int i, int64_t c) { return static_cast<char*>(ops[i].host) + (size_t)(c * chunk_blocks) * ops[i].stride; };

@@ -63,6 +63,7 @@ def lib():
         "gfdm_hip_get_host_pipeline": (i32, [vp, vp, vp, vp, vp]),
         "gfdm_hip_host_call_stats": (i32, [vp, vp, vp, vp, vp, vp]),
         "gfdm_hip_host_call_times": (i32, [vp]),
+        "gfdm_hip_set_host_streaming_copies_for_testing": (i32, [i32]),
         "gfdm_hip_modulator_create": (i32, [ctypes.POINTER(vp), i32, i32, i32, vp, i32, i32]),
         "gfdm_hip_modulator_destroy": (i32, [vp]),
         "gfdm_hip_modulator_block_size": (i32, [vp]),

@@ -154,6 +154,9 @@ int gfdm_hip_host_call_stats(int64_t* chunks, int64_t* chunk_blocks, int64_t* st
 /* ... and where the calling thread spent it, nanoseconds: ns5[0] sorting the operands and sizing the staging, [1] bounce copies, [2] enqueueing
  * the kernels, [3] posting completion tickets, [4] waiting for them.  (A one-block call on the MI355X box: 0.3 / 0.4 / 3.8 / 3.1 / 5.1 us.) */
 int gfdm_hip_host_call_times(int64_t* ns5);
+/* TEST / MEASUREMENT HOOK: the bounce copies of calls that stage 2 MiB or more use non-temporal (streaming) stores; 0 = plain memcpy everywhere
+ * (A/B).  Returns the previous setting. */
+int gfdm_hip_set_host_streaming_copies_for_testing(int enable);
 
 /* ---- modulator_kernel_cc (include/gfdm/modulator_kernel_cc.h:41-51) -------------------- */
 

@@ -351,3 +351,35 @@ def test_memory_pinned_or_owned_by_somebody_else(pipeline):
     od = torch.empty_like(xd)
     assert g.lib().gfdm_hip_receiver_demodulate_host(dem._h, ctypes.c_void_p(od.data_ptr()), ctypes.c_void_p(xd.data_ptr()), None, ctypes.c_int64(nb)) == 0
     assert g.host_call_stats()["direct_mask"] == 0b11 and np.array_equal(od.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("threads", [0, 3])
+def test_streaming_store_copies_move_the_same_bytes_from_and_to_unaligned_buffers(pipeline, threads):
+    """Calls that stage 2 MiB or more copy with non-temporal stores (gfdm_hostpipe.hip: copy_streaming_avx2, destination aligned to 32 bytes with
+    a memcpy'd head and tail).  Buffers that start 8 bytes off any alignment, chunk sizes that leave ragged pieces: equal to the plain-memcpy
+    route and to the device path, and nothing written outside the output."""
+    g = pipeline
+    M, K, L = 9, 64, 2
+    N = M * K
+    dem = g.Demodulator(M, K, L, get_frequency_domain_filter("rrc", 0.2, M, K, L))
+    nb = 1200                                       # 5.5 MB in, 5.5 MB out
+    rng = np.random.default_rng(21)
+    raw_in = np.zeros(nb * N + 7, np.complex64)
+    raw_out = np.full(nb * N + 7, np.complex64(77 - 5j))
+    ref = None
+    for off in (0, 1, 3):                           # complex64 elements: 0, 8, 24 bytes off the allocation's alignment
+        x = raw_in[off:off + nb * N].reshape(nb, N)
+        x[...] = qpsk(rng, (nb, N))
+        want = device_reference(dem.demodulate, x)
+        for chunk in (0, 999_983, 3 << 20):
+            for streaming in (1, 0):
+                g.set_host_pipeline(0, chunk, 3, threads, 2)
+                prev = g.lib().gfdm_hip_set_host_streaming_copies_for_testing(streaming)
+                try:
+                    raw_out[...] = np.complex64(77 - 5j)
+                    y = raw_out[off:off + nb * N].reshape(nb, N)
+                    dem.demodulate(x, out=y)
+                finally:
+                    g.lib().gfdm_hip_set_host_streaming_copies_for_testing(prev)
+                assert np.array_equal(y, want), (off, chunk, streaming)
+                assert np.all(raw_out[:off] == np.complex64(77 - 5j)) and np.all(raw_out[off + nb * N:] == np.complex64(77 - 5j))
