@@ -58,7 +58,8 @@ constexpr size_t lds_bytes(int K, int M) { return (size_t)bpw(K) * (size_t)tile_
 constexpr bool ic_mfma(int K, int M) { return pow2(K) && K >= 16 && M >= 4 && M <= 16; }
 // ... and where it is the default (measured, profiles/README.md)
 constexpr bool ic_mfma_preferred(int K, int M) { return ic_mfma(K, M) && K >= 128; }
-constexpr size_t ic_mfma_edge_bytes(int K) { return wave_local(K) ? 0 : (size_t)2 * (K / 64) * 2 * 2 * 4 * 8; }
+constexpr size_t ic_mfma_pad_bytes(int K) { return wave_local(K) ? 0 : (size_t)(K / 4) * 8; }      // padding of the rounds' tile layout (one element per 4 rows)
+constexpr size_t ic_mfma_edge_bytes(int K) { return wave_local(K) ? 0 : (size_t)2 * (K / 64) * 2 * 2 * 4 * 8 + ic_mfma_pad_bytes(K); }
 constexpr int est_stride(int K) { return K + 10; }                           // EQ_PREAMBLE: edge-extended estimate bins per block
 constexpr size_t est_bytes(int K) { return (size_t)bpw(K) * (size_t)est_stride(K) * 8; }
 

@@ -559,7 +559,15 @@ template <int K, int M> struct IcMfma {
     static constexpr int G = KW / 16;                         // 16-row groups (lane rows) per block and wavefront: 1, 2, 4
     static constexpr int W = K > 64 ? K / 64 : 1;             // wavefronts per block
     static constexpr bool MULTI = !rowgeom::wave_local(K);    // K >= 128: the wavefronts' edge rows cross LDS, one barrier per round
-    static constexpr int EDGE = (int)rowgeom::ic_mfma_edge_bytes(K) / 2;   // one of the two edge buffers, bytes
+    static constexpr int EDGE = (int)(rowgeom::ic_mfma_edge_bytes(K) - rowgeom::ic_mfma_pad_bytes(K)) / 2;   // one of the two edge buffers, bytes
+    // The tile from the rounds on: [row][M] with ONE element of padding behind every G rows.  A lane row of the C / D operands holds rows G cn + g, i.e. its 16
+    // lanes step by G M elements -- an even number, so without the padding the 64 lanes of an access fall on 8 of the 32 b64 slots; with it the step is odd
+    // (same-box A/B, profiles/r04/ic_tile_padding_ab.txt: K=128 M=15 L=4 MF + 2 IC 61.9 -> 59.3 us per 8192 blocks, 456 -> 445 us per 65 536).  The padding lies
+    // in the 16 spare elements between the tiles of a workgroup (K <= 64) or behind the tile (rowgeom::ic_mfma_pad_bytes).
+    static constexpr int PADSH = G == 4 ? 2 : G == 2 ? 1 : 0;
+    static constexpr int PADD = ((G * M) % 2 == 0) ? 1 : 0;
+    static __device__ __forceinline__ int pa(int r, int m) { return r * M + m + (PADD ? (r >> PADSH) : 0); }
+    static __device__ __forceinline__ int pa_linear(int e) { return e + (PADD ? ((e / M) >> PADSH) : 0); }
     // the row of its block that lane q of the block works on from phase D on (kIcRegTranspose)
     static __device__ __forceinline__ int row_of(int q)
     {
@@ -629,12 +637,12 @@ template <int K, int M> struct IcMfma {
         const ic_h8 afrag = __builtin_bit_cast(ic_h8, pre.a), afrag2 = __builtin_bit_cast(ic_h8, pre.a2);
         ic_f4 c0[4][2], cur[4][2];
         if constexpr (!kIcRegTranspose) {
-            // d0 through the block's tile: rows in natural order in, timeslots 4 cr .. 4 cr + 3 of rows wbase + G cn + g out
-            static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[q * M + m] = d[m]; });
+            // d0 through the block's tile (padded layout pa): rows in natural order in, timeslots 4 cr .. 4 cr + 3 of rows wbase + G cn + g out
+            static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; X[pa(q, m)] = d[m]; });
             block_sync<K>();
             static_for<0, 4>([&](auto gi) {
                 constexpr int g4 = decltype(gi)::value;
-                const cf* row = reinterpret_cast<const cf*>(blk0) + grp_block(g4) * TS + (wbase + G * cn + (g4 % G)) * M + 4 * cr;
+                const cf* row = reinterpret_cast<const cf*>(blk0) + grp_block(g4) * TS + pa(wbase + G * cn + (g4 % G), 4 * cr);
                 static_for<0, 4>([&](auto ii) {
                     constexpr int i = decltype(ii)::value;
                     cf v = mk(0.f, 0.f);
@@ -701,10 +709,10 @@ template <int K, int M> struct IcMfma {
                 });
             });
         }
-        // result -> the tile in natural order [k][M]: group g4 of lane (cr, cn) is row wbase + G cn + g4 % G of block grp_block(g4)
+        // result -> the tile, [k][M] in the padded layout (the kernel's linear read for the coalesced store uses pa_linear): group g4 of lane (cr, cn) is row wbase + G cn + g4 % G of block grp_block(g4)
         static_for<0, 4>([&](auto gi) {
             constexpr int g4 = decltype(gi)::value;
-            cf* row = reinterpret_cast<cf*>(blk0) + grp_block(g4) * TS + (wbase + G * cn + (g4 % G)) * M + 4 * cr;
+            cf* row = reinterpret_cast<cf*>(blk0) + grp_block(g4) * TS + pa(wbase + G * cn + (g4 % G), 4 * cr);
             static_for<0, 4>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
                 if (12 + i < M || 4 * cr + i < M) row[i] = mk(cur[g4][0][i], cur[g4][1][i]);     // (first form: known at compile time for every lane)
@@ -920,7 +928,7 @@ __global__ __launch_bounds__(RowShape<K>::WG, ((MODE == RX_IC && ICK == ICK_MFMA
 
     if constexpr (ICMX) {
         constexpr size_t edge_off = (EQ == EQ_PREAMBLE) ? row_lds_bytes<K, MS>() + EstTile<K>::bytes : row_lds_bytes<K, M>();
-        IcMfma<K, M>::template rounds<T::TS>(smem, smem + edge_off, X, q, d, icpre, ic_iter);
+        IcMfma<K, M>::template rounds<T::TS>(smem, smem + edge_off + rowgeom::ic_mfma_pad_bytes(K), X, q, d, icpre, ic_iter);
     } else if constexpr (MODE == RX_IC) {
         // One cancellation round of the reference is  d_new = IDFT_M(S - ic (.) DFT_M(nb)) / M  with nb = dec_{k-1} + dec_{k+1}.
         // Both transforms are linear, so  d_new = d0 - g (*) nb  with d0 = IDFT_M(S)/M (already in d) and the M-tap circular
@@ -1031,7 +1039,7 @@ __global__ __launch_bounds__(RowShape<K>::WG, ((MODE == RX_IC && ICK == ICK_MFMA
         // resource demapper fused into the store: only active subcarriers, in mapper order; for per-timeslot order the lanes of
         // one timeslot write consecutive output symbols, so no LDS staging is needed                     mapper:91-106,136-163
         const int a = rank_q;
-        if constexpr (ICMX) static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d[m] = X[q * M + m]; });
+        if constexpr (ICMX) static_for<0, M>([&](auto mi) { constexpr int m = decltype(mi)::value; d[m] = X[IcMfma<ICMX ? K : 16, ICMX ? M : 4>::pa(q, m)]; });
         if (valid && a >= 0) {
             cf* o = out + blk * (int64_t)io_nout;
             static_for<0, M>([&](auto mi) {
@@ -1047,7 +1055,8 @@ __global__ __launch_bounds__(RowShape<K>::WG, ((MODE == RX_IC && ICK == ICK_MFMA
             block_sync<K>();
         }
         if (valid) {
-            static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; st_stream(out, base + q + K * i, X[q + K * i]); });
+            if constexpr (ICMX) static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; st_stream(out, base + q + K * i, X[IcMfma<ICMX ? K : 16, ICMX ? M : 4>::pa_linear(q + K * i)]); });
+            else static_for<0, M>([&](auto ii) { constexpr int i = decltype(ii)::value; st_stream(out, base + q + K * i, X[q + K * i]); });
         }
     }
     GFDM_STAMP(5);

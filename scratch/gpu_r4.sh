@@ -90,16 +90,18 @@ icab)   # same-box A/B of the cancellation kernels: working tree, the register-t
   trace $O/ic_ab.csv tree_64_9_2_dpp_mf_ic2_4096 200 demod_mf_ic2 4096 400 36
   cut -d, -f1,7-9 $O/ic_ab.csv
   cd $R; timeout 900 python -m pytest tests/test_parity_gpu.py -x -q -k "ic or matrix or zero or golden" > $O/pytest_ic.txt 2>&1; tail -3 $O/pytest_ic.txt ;;
-icw)    # same-box A/B: five waves per SIMD asked of the matrix-core IC kernels (tree) against the unconstrained registers (scratch/ab/w2)
-  echo "label,kernel,workgroups,workgroup_size,queue,launches,mean_us,median_us,min_us,max_us" > $O/ic_waves_ab.csv
+icw)    # same-box A/B of the matrix-core IC kernels: the tree against a variant library scratch/ab/<variant>/ (third argument; parity tests on the variant first)
+  V=${3:-w2}
+  cd $R; GFDM_HIP_LIB=$R/scratch/ab/$V/libgfdm_hip.so timeout 900 python -m pytest tests/test_parity_gpu.py -x -q -k "ic or matrix or zero or golden" > $O/pytest_ic_$V.txt 2>&1; tail -3 $O/pytest_ic_$V.txt; cd /tmp
+  echo "label,kernel,workgroups,workgroup_size,queue,launches,mean_us,median_us,min_us,max_us" > $O/ic_ab_$V.csv
   for rep in 1 2 3; do
-  for v in tree w2; do
+  for v in tree $V; do
     unset GFDM_HIP_LIB
-    [ $v = w2 ] && export GFDM_HIP_LIB=$R/scratch/ab/w2/libgfdm_hip.so
-    for b in 8192 65536; do trace $O/ic_waves_ab.csv ${v}_128_15_4_mf_ic2_${b}_$rep 20 demod_mf_ic2 $b 40 2 128 15 4; trace $O/ic_waves_ab.csv ${v}_128_15_4_zf_ic2_${b}_$rep 20 demod_zf_ic2 $b 40 2 128 15 4; done
-    GFDM_MX=2 trace $O/ic_waves_ab.csv ${v}_64_9_2_mx2_mf_ic2_4096_$rep 200 demod_mf_ic2 4096 400 36
+    [ $v = $V ] && export GFDM_HIP_LIB=$R/scratch/ab/$V/libgfdm_hip.so
+    for b in 8192 65536; do trace $O/ic_ab_$V.csv ${v}_128_15_4_mf_ic2_${b}_$rep 20 demod_mf_ic2 $b 40 2 128 15 4; trace $O/ic_ab_$V.csv ${v}_128_15_4_zf_ic2_${b}_$rep 20 demod_zf_ic2 $b 40 2 128 15 4; done
+    GFDM_MX=2 trace $O/ic_ab_$V.csv ${v}_64_9_2_mx2_mf_ic2_4096_$rep 200 demod_mf_ic2 4096 400 36
   done; done
   unset GFDM_HIP_LIB
-  cut -d, -f1,7-9 $O/ic_waves_ab.csv ;;
+  cut -d, -f1,7-9 $O/ic_ab_$V.csv ;;
 *) echo "unknown task $1"; exit 2 ;;
 esac
