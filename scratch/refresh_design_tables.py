@@ -20,7 +20,7 @@ def c2(shape, p):
     a = cell("%s_%s_8192" % (shape, p)); b = cell("%s_%s_65536" % (shape, p))
     return "%.1f us (%.1f) = **%.1f %%**" % (a[0], a[1], a[3]), "%.1f us = **%.1f %%**" % (b[0], b[3])
 x = c2("128_15_4", "demod_mf"); t2.append("| K=128 M=15 L=4 | MF demod | %s | %s | 50.7 / 377 us |" % x)
-x = c2("128_15_4", "demod_mf_ic2"); t2.append("| K=128 M=15 L=4 | **MF + 2 IC (configs[3])**, rounds on the matrix cores (default) | %s; same-box A/B of the tile padding 61.9 -> 59.3; before the padding, four collections: 60.7-62.4 | %s; A/B 456 -> 445; before: 450-456 | 62.7 us = 50.2 %% / 466.6 us = 53.9 %% |" % x)
+x = c2("128_15_4", "demod_mf_ic2"); t2.append("| K=128 M=15 L=4 | **MF + 2 IC (configs[3])**, rounds on the matrix cores (default) | %s; another box 60.0 (`ic_wave_local_store_ab.txt`), same-box A/B of the tile padding 61.9 -> 59.3; before the padding, four collections: 60.7-62.4 | %s; another box 445; A/B 456 -> 445; before: 450-456 | 62.7 us = 50.2 %% / 466.6 us = 53.9 %% |" % x)
 t2.append("| K=128 M=15 L=4 | the same with the rounds on the vector ALU (`set_ic_matrix_cores(0)`; kernel unchanged since round 3) | 66.7-72.7 us over the boxes = 43-47 % | 518-521 us = 48 % | 66.7 / 518.6 us |")
 x = c2("128_15_4", "demod_zf_ic2"); t2.append("| K=128 M=15 L=4 | ZF + 2 IC, matrix cores | %s | %s | 73.6 us = 64.1 %% / 564 us = 66.9 %% |" % x)
 a = c2("256_31_2", "demod_mf"); b = c2("256_31_2", "modulate")
