@@ -103,5 +103,17 @@ icw)    # same-box A/B of the matrix-core IC kernels: the tree against a variant
   done; done
   unset GFDM_HIP_LIB
   cut -d, -f1,7-9 $O/ic_ab_$V.csv ;;
+modab)  # same-box A/B of the K=128 M=15 L=4 modulator: the tree against scratch/ab/<variant>/ (third argument)
+  V=${3:-m5}
+  cd $R; GFDM_HIP_LIB=$R/scratch/ab/$V/libgfdm_hip.so timeout 900 python -m pytest tests/test_parity_gpu.py -x -q -k "golden_modulator or full_size" > $O/pytest_mod_$V.txt 2>&1; tail -3 $O/pytest_mod_$V.txt; cd /tmp
+  echo "label,kernel,workgroups,workgroup_size,queue,launches,mean_us,median_us,min_us,max_us" > $O/mod_ab_$V.csv
+  for rep in 1 2 3; do
+  for v in tree $V; do
+    unset GFDM_HIP_LIB
+    [ $v = $V ] && export GFDM_HIP_LIB=$R/scratch/ab/$V/libgfdm_hip.so
+    for b in 8192 65536; do trace $O/mod_ab_$V.csv ${v}_128_15_4_modulate_${b}_$rep 20 modulate $b 40 2 128 15 4; done
+  done; done
+  unset GFDM_HIP_LIB
+  cut -d, -f1,7-9 $O/mod_ab_$V.csv ;;
 *) echo "unknown task $1"; exit 2 ;;
 esac
