@@ -495,7 +495,9 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
 
     // bounce copies: the chunks of a large call go to the copy pool as jobs (the bytes of one chunk, in and out, decide); a small call -- the
     // one-block call of a GNU Radio wrapper -- copies on the spot, no job object, no allocation
-    const bool pooled = helpers > 0 && host_bytes >= kPoolMinBytes;
+    // (a call that is ONE chunk never goes to the pool: its copies are at most 1 MiB in all, and waking the helpers costs more than they take over --
+    // 64 blocks of K=64 M=9 per call: 38-41 us pooled, 34 us on the calling thread, profiles/r04/host_mid_size_calls.txt)
+    const bool pooled = helpers > 0 && host_bytes >= kPoolMinBytes && nchunks > 1;
     const bool streaming = total_staged >= kStreamCallBytes && g_have_avx2 && g_streaming_copies.load(std::memory_order_relaxed) != 0;
     std::shared_ptr<CopyJob> job;
     auto job_add = [&](char* dst, const char* src, size_t n) {

@@ -730,8 +730,10 @@ template <int K, int M> struct IcMfma {
 // VGPRs, which the dead registers of the FFT phases provide; with the default bound it takes 64 AGPRs ON TOP: 108 + 64 registers = 2 waves
 // per SIMD instead of 120 = 4)
 // GFDM_IC_WAVES_PER_SIMD: since round 4 the rounds need no LDS beyond the tile, so at K=128 M=15 the LDS would let a CU hold ten blocks = five waves per SIMD
-// where the kernel's 98-104 registers hold it at eight.  Asking for five (96 registers, 6-11 of them spilled) measured SLOWER on one box
+// where the kernel's 98-104 registers held it at eight.  Asking for five (96 registers, 6-11 of them spilled) measured SLOWER on one box
 // (profiles/r04/ic_waves_per_simd_ab.txt: MF + 2 IC 65.4 against 63.2 us per 8192 blocks, 467 against 457 us per 65 536; ZF + 2 IC 84 against 75 us): the default stays 2.
+// (With the padded tile the MF + 2 IC kernel of that shape compiles to 96 registers by itself; ZF + 2 IC keeps 105, and its five-wave form with the equaliser vector
+// requested late is slower as well: profiles/r04/ic_zf_late_equaliser_ab.txt.)
 #ifndef GFDM_IC_WAVES_PER_SIMD
 #define GFDM_IC_WAVES_PER_SIMD 2
 #endif

@@ -124,3 +124,17 @@ the GPU reports back), more than the CPU's 4.2 us: the GPU pays off through the 
 s = s[:a] + new + s[b:]
 open(p, 'w').write(s)
 print("narrative numbers refreshed")
+
+# ---- dominant kernels against torch's copy of the same bytes
+rows = ["| `bench.py --config` | dominant kernel, blocks per launch | achieved | copy of the same bytes | kernel / copy | `frac` of 8 TB/s | HBM traffic / algorithmic bytes (PMC) |", "|---|---|---|---|---|---|---|"]
+for f, name in (("bench_default", "default (configs[1]) | modulate K=64 M=9, 4096"), ("bench_cfg3", "cfg3 (configs[2], north star) | ZF + 2 IC K=64 M=9, 4096"),
+                ("bench_cfg4", "cfg4 (configs[3]) | MF + 2 IC K=128 M=15 L=4, 65 536"), ("bench_cfg5", "cfg5 (configs[4]) | ZF K=256 M=31, 65 536")):
+    rr = json.load(open(os.path.join(D, f + '.json')))['roofline']
+    tr = ("%.3f" % (rr['traffic'] / rr['bytes_per_launch'])) if rr.get('traffic') else "n/a"
+    rows.append("| %s | %.2f TB/s | %.2f TB/s | %.2f | %.1f %% | %s |" % (name, rr['achieved'] / 1e3, rr['copy_ceiling_GBps'] / 1e3, rr['achieved'] / rr['copy_ceiling_GBps'], 100 * rr['frac'], tr))
+p2 = os.path.join(ROOT, 'DESIGN.md')
+s2 = open(p2).read()
+a = s2.index('| `bench.py --config` | dominant kernel, blocks per launch | achieved |'); b = s2.index("(`torch`'s copy is a reference point")
+s2 = s2[:a] + '\n'.join(rows) + '\n\n' + s2[b:]
+open(p2, 'w').write(s2)
+print("copy table refreshed")
