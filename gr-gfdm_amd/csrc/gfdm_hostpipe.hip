@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -21,19 +22,21 @@ namespace {
 // how the bytes cross the link: 0 under the kernels' own accesses to host memory, 1 copy engines + device staging, 2 inputs under the
 // kernel's reads and outputs by copy engine, 3 the reverse (HostPipe::run)
 std::atomic<int> g_mode{ 0 };
-// bytes of all staged operands per chunk; 0 = automatic (one chunk up to kSingleChunkMax, else total / 8 within [kAutoMin, kAutoMax]:
-// profiles/r04/host_path_sweep.txt -- 4 MiB chunks are best for a 4096-block call, 16 MiB for 65 536 blocks)
+// bytes of all staged operands per chunk; 0 = automatic: one chunk up to kSingleChunkMax, else round(sqrt(1.3 x MiB staged)) chunks, at least two, of at most
+// kAutoMax.  The calling thread does copies, launches and tickets one after the other, so a call takes about (copies + ~7 us per chunk + the last chunk's time on
+// the GPU): the minimum over the number of chunks n lies near sqrt(GPU time / 7 us).  profiles/r04/host_chunk_sweep.txt: two chunks from 0.5 to 3.5 MB, 3-6 up to
+// 20 MB, 8-10 at 40-55 MB (the round's first rule, total / 8 but at least 512 KiB, cut a 256-block call into five: 104-109 us against 77-81 us with two).
 std::atomic<int64_t> g_chunk_bytes{ 0 };
 std::atomic<int> g_depth{ 3 };
 std::atomic<int> g_copy_threads{ 3 };
 std::atomic<int> g_kernel_streams{ 2 };         // mode 0: chunks alternate between this many streams (1 or 2)
 
-constexpr size_t kSingleChunkMax = 1u << 20;    // a call that stages at most this much is one chunk (measured crossover 1.2-1.5 MB, round 2)
-constexpr size_t kAutoMin = 512u << 10, kAutoMax = 16u << 20;
+constexpr size_t kSingleChunkMax = 512u << 10;  // a call that stages at most this much is one chunk
+constexpr size_t kAutoMax = 16u << 20;
 constexpr size_t kAlign = 256;
 constexpr size_t kSliceBytes = 256u << 10;      // unit of work of the copy pool
 #ifndef GFDM_HOST_POOL_MIN_BYTES
-#define GFDM_HOST_POOL_MIN_BYTES (512u << 10)
+#define GFDM_HOST_POOL_MIN_BYTES (1u << 20)
 #endif
 constexpr size_t kPoolMinBytes = GFDM_HOST_POOL_MIN_BYTES;    // smaller copy jobs stay on the calling thread
 constexpr int64_t kMaxLaunchBlocks = 1 << 30;
@@ -450,9 +453,11 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
     else if (chunk_bytes == 0) {
         if (plan_total <= kSingleChunkMax) chunk_blocks = nblocks;
         else {
-            chunk_bytes = plan_total / 8;
-            chunk_bytes = chunk_bytes < kAutoMin ? kAutoMin : chunk_bytes > kAutoMax ? kAutoMax : chunk_bytes;
-            chunk_blocks = (int64_t)(chunk_bytes / (plan_per_block ? plan_per_block : 1));
+            int64_t n = (int64_t)(sqrt(1.3 * (double)plan_total / 1048576.0) + 0.5);
+            if (n < 2) n = 2;
+            chunk_blocks = (nblocks + n - 1) / n;
+            const int64_t cap = (int64_t)(kAutoMax / (plan_per_block ? plan_per_block : 1));
+            if (chunk_blocks > cap) chunk_blocks = cap;
         }
     } else {
         chunk_blocks = (int64_t)(chunk_bytes / (plan_per_block ? plan_per_block : 1));
@@ -495,8 +500,8 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
 
     // bounce copies: the chunks of a large call go to the copy pool as jobs (the bytes of one chunk, in and out, decide); a small call -- the
     // one-block call of a GNU Radio wrapper -- copies on the spot, no job object, no allocation
-    // (a call that is ONE chunk never goes to the pool: its copies are at most 1 MiB in all, and waking the helpers costs more than they take over --
-    // 64 blocks of K=64 M=9 per call: 38-41 us pooled, 34 us on the calling thread, profiles/r04/host_mid_size_calls.txt)
+    // (copy jobs below 1 MiB stay on the calling thread: waking the helpers costs more than they take over -- 64 blocks of K=64 M=9 per call: 38-41 us pooled,
+    // 34 us on the calling thread, profiles/r04/host_mid_size_calls.txt; three 590 KB chunks 95-97 us pooled, 72 us not, profiles/r04/host_chunk_sweep.txt)
     const bool pooled = helpers > 0 && host_bytes >= kPoolMinBytes && nchunks > 1;
     const bool streaming = total_staged >= kStreamCallBytes && g_have_avx2 && g_streaming_copies.load(std::memory_order_relaxed) != 0;
     std::shared_ptr<CopyJob> job;

@@ -127,7 +127,7 @@ const char* gfdm_hip_build_id(void);
  *     used IN PLACE: the kernels run on the caller's memory, bound by the link (~57 GB/s each way on the MI355X boxes);
  *   - ordinary pageable buffers are bounced through pinned staging sets in chunks: the kernel of chunk c works across the link
  *     while the calling thread and a small pool of copy threads move chunk c + 1 in and chunk c - 1 out.  A call that fits one
- *     chunk (<= 1 MiB, e.g. the one block per call of an unchanged GNU Radio wrapper) is copy in, one launch, completion ticket, copy out.
+ *     chunk (<= 512 KiB, e.g. the one block per call of an unchanged GNU Radio wrapper) is copy in, one launch, completion ticket, copy out.
  *   Measured (MI355X box, K=64 M=9, profiles/r04/bench_default.json): pageable 6.4 M blocks/s matched filter, 4.3 M ZF + 2 IC at 65 536 blocks
  *   per call; registered 9.6 M / 6.0 M (88 / 82 GB/s over the link, both directions together); one block per call 13-16 us either way.
  * Results do not depend on the route (same kernels, same blocks).  The call returns when `out` is complete.
@@ -142,8 +142,9 @@ int gfdm_hip_unregister_host(void* ptr);
  * accesses to the pinned staging memory, 1 copy engines (H2D / kernel / D2H on three streams, device staging), 2 inputs under the kernel's
  * reads and outputs by copy engine, 3 the reverse -- 1 .. 3 are kept for A/B measurements (profiles/r04/host_path_sweep.txt: mode 0 wins
  * or ties everywhere but the largest matched-filter calls); chunk_bytes = staged bytes per chunk over all operands, 0 = automatic (one chunk
- * up to 1 MiB, else total / 8 within 512 KiB .. 16 MiB); depth = staging sets (1 .. 4, default 3); copy_threads = pool threads that help the
- * calling thread with the bounce copies of chunks >= 512 KiB (0 .. 16, default 3); kernel_streams = 2 (default): the chunks alternate
+ * up to 512 KiB, else about sqrt(1.3 x MiB staged) chunks, at least two, of at most 16 MiB: profiles/r04/host_chunk_sweep.txt); depth = staging
+ * sets (1 .. 4, default 3); copy_threads = pool threads that help the calling thread with the bounce copies of chunks >= 1 MiB (0 .. 16,
+ * default 3); kernel_streams = 2 (default): the chunks alternate
  * between two streams (a kernel reads its blocks, then writes them, i.e. uses one direction of the link at a time; with two streams the
  * reads of one chunk can run under the writes of another), 1 = a single stream. */
 int gfdm_hip_set_host_pipeline(int mode, int64_t chunk_bytes, int depth, int copy_threads, int kernel_streams);

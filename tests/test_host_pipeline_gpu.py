@@ -383,3 +383,21 @@ def test_streaming_store_copies_move_the_same_bytes_from_and_to_unaligned_buffer
                     g.lib().gfdm_hip_set_host_streaming_copies_for_testing(prev)
                 assert np.array_equal(y, want), (off, chunk, streaming)
                 assert np.all(raw_out[:off] == np.complex64(77 - 5j)) and np.all(raw_out[off + nb * N:] == np.complex64(77 - 5j))
+
+
+def test_automatic_chunk_plan_of_small_and_mid_size_calls(pipeline):
+    """chunk_bytes = 0: one chunk up to 512 KiB of staged bytes, else round(sqrt(1.3 x MiB staged)) chunks, at least two (gfdm_hostpipe.hip; the measured
+    optimum of profiles/r04/host_chunk_sweep.txt).  K=64 M=9 MF demodulation stages 9216 bytes per block."""
+    g = pipeline
+    g.set_host_pipeline(0, 0, 3, 3, 2)
+    M, K, L = 9, 64, 2
+    N = M * K
+    dem = g.Demodulator(M, K, L, get_frequency_domain_filter("rrc", 0.2, M, K, L))
+    x = qpsk(np.random.default_rng(31), (4096, N))
+    want = device_reference(dem.demodulate, x)
+    for nb, chunks in ((1, 1), (48, 1), (56, 1), (57, 2), (64, 2), (257, 2), (512, 2), (1024, 3), (4096, 7)):
+        out = dem.demodulate(x[:nb])
+        st = g.host_call_stats()
+        assert st["chunks"] == chunks and st["chunk_blocks"] == -(-nb // chunks), (nb, st)
+        assert (st["copy_threads"] >= 1) == (st["chunk_blocks"] * 2 * N * 8 >= (1 << 20)), (nb, st)      # the pool takes copy jobs of 1 MiB and more
+        assert np.array_equal(out, want[:nb]), nb
