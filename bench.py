@@ -90,7 +90,8 @@ def parse(argv=None):
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--batch", type=int, default=None, help="override: blocks per step and per GPU (weak configs) or in total (strong configs)")
     ap.add_argument("--ring-mib", type=int, default=2048, help="total footprint of the buffer ring per path")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the independent steps of the headline loop are pipelined over")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the independent steps of the headline loop are pipelined over (3 and 4 sustain the same rate, 3 starts a burst 3 %% faster: profiles/r04/bench_streams_sweep.txt)")
     ap.add_argument("--large-batch", type=int, default=65536, help="blocks per launch of the extra large-batch measurement (0 = skip)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained run of the headline loop (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -69,17 +69,17 @@ s = open(p).read()
 a = s.index('Headline (`bench.py`, configs[1], step = modulate + MF demodulate of 4096 blocks, `profiles/r04/bench_default.json`)')
 b = s.index('## 7. Where the time goes')
 new = '''Headline (`bench.py`, configs[1], step = modulate + MF demodulate of 4096 blocks, `profiles/r04/bench_default.json`): **%.0f M blocks/s** in the 200-step burst with the
-independent steps pipelined over 4 HIP streams -- the demodulator of a step works on the frames modulated FOUR STEPS EARLIER (302 MB of other traffic in between, more than the
-256 MiB Infinity Cache; every step is still one modulate + one demodulate of a whole batch); demodulating the frames the same step has just written gives %.0f M, i.e. the
+independent steps pipelined over %d HIP streams (three or four sustain the same rate, three start a burst 3 %% faster: `profiles/r04/bench_streams_sweep.txt`) -- the demodulator
+of a step works on the frames modulated %d steps EARLIER (%.0f MB of other traffic in between, more than the 256 MiB Infinity Cache; every step is still one modulate + one demodulate of a whole batch); demodulating the frames the same step has just written gives %.0f M, i.e. the
 cache makes no measurable difference -- , **%.0f M blocks/s = %.0f GSym/s sustained over 1.9 s**, %.0f M on one stream (the boxes of the pool: 280-289 / 292-301 M).  CPU beside it
 (same box, plain-C port of the reference algorithm, one kernel object per pinned pthread, set-up not timed, `oracle/gfdm_oracle_bench.c`): **%.2f M blocks/s on 16 threads** -- the
 process sees 256 logical CPUs of 2 x EPYC 9575F in its affinity mask but its cgroup grants 16 CPUs' worth of run time (`cpu.max`); `bench.py` reads the quota, runs that many threads
 and reports `cores`, `cgroup_cpu_quota`, `scaling_vs_single_thread`.  The other configurations (`bench.py --config`, burst / sustained): cfg3 %.0f / %.0f M blocks/s -- the north-star
-path with independent batches pipelined over four streams moves %.0f M x 13 824 B = %.1f TB/s of algorithmic bytes, **%.0f %% of the HBM peak** (a single 4096-block launch alone on the
+path with independent batches pipelined over the same number of streams moves %.0f M x 13 824 B = %.1f TB/s of algorithmic bytes, **%.0f %% of the HBM peak** (a single 4096-block launch alone on the
 GPU: 46-51 %%) --, cfg4 %.0f / %.0f M blocks/s (65 536 blocks per step on ONE GPU; dominant kernel %.0f us = %.1f %%), cfg5 %.1f / %.1f M blocks/s (%.0f us = %.1f %%).
 `bench.py`'s headline hands device-resident buffers to the kernels; the host-buffer entry points are measured beside it (`paths.host_batch_*`, section 16).
 
-''' % (r['value'] / 1e6, r['value_same_slot'] / 1e6, r['sustained']['value'] / 1e6, r['sustained']['value'] * 576 / 1e9, r['value_single_stream'] / 1e6, r['cpu_baseline']['value'] / 1e6,
+''' % (r['value'] / 1e6, r['config']['streams'], r['demod_lag_steps'], r['demod_lag_steps'] * 32 * 576 * 4096 / 1e6, r['value_same_slot'] / 1e6, r['sustained']['value'] / 1e6, r['sustained']['value'] * 576 / 1e9, r['value_single_stream'] / 1e6, r['cpu_baseline']['value'] / 1e6,
        c3['value'] / 1e6, c3['sustained']['value'] / 1e6, c3['sustained']['value'] / 1e6, c3['sustained']['value'] * 13824 / 1e12, 100 * c3['sustained']['value'] * 13824 / 8e12,
        c4['value'] / 1e6, c4['sustained']['value'] / 1e6, c4['roofline']['kernel_ms'] * 1e3, 100 * c4['roofline']['frac'], c5['value'] / 1e6, c5['sustained']['value'] / 1e6,
        c5['roofline']['kernel_ms'] * 1e3, 100 * c5['roofline']['frac'])
