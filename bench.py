@@ -85,8 +85,8 @@ GEN_CHUNK = 8192              # blocks per chunk of the on-device input generati
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 20 for the strong-scaled cfg4 / cfg5)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; 10 for cfg4 / cfg5)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 100 for the strong-scaled cfg4 / cfg5: 20 steps are a 10 ms region that ends before the launches overlap steadily, profiles/r04/bench_steps_sweep.txt)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--batch", type=int, default=None, help="override: blocks per step and per GPU (weak configs) or in total (strong configs)")
     ap.add_argument("--ring-mib", type=int, default=2048, help="total footprint of the buffer ring per path")
@@ -110,9 +110,9 @@ def parse(argv=None):
     a = ap.parse_args(argv)
     strong = CONFIGS[a.config]["total"] is not None
     if a.steps is None:
-        a.steps = 20 if strong else 200
+        a.steps = 100 if strong else 200
     if a.warmup is None:
-        a.warmup = 10 if strong else 20
+        a.warmup = 20
     return a
 
 
@@ -205,11 +205,16 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
     import torch
     import torch.distributed as dist
     nslots = len(step_fns)
+    early_gc = os.environ.get("GFDM_BENCH_EARLY_GC", "1") != "0"
+    if early_gc:
+        gc.collect()                          # before the warm-up steps, so that the GPU does not sit idle through a collection between them and the timed region
+        gc.disable()                          # no collector pause (tens of ms with the tensor rings alive) inside the timed region
     for i in range(warmup):
         for f in step_fns[i % nslots]:
             f()
-    gc.collect()
-    gc.disable()                              # no collector pause (tens of ms with the tensor rings alive) inside the timed region
+    if not early_gc:
+        gc.collect()
+        gc.disable()
     dist_on = dist.is_available() and dist.is_initialized()      # also a one-rank group (--force-dist / torchrun --nproc-per-node 1)
     torch.cuda.synchronize()
     if dist_on:

@@ -22,7 +22,9 @@ tests)
 bench)
   cd $R
   python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-300 $O/bench_default.json
-  for c in cfg3 cfg4 cfg5; do python3 bench.py --config $c --no-cpu-baseline --no-host-paths > $O/bench_$c.json 2>/dev/null; cut -c1-200 $O/bench_$c.json; done ;;
+  for c in cfg3 cfg4 cfg5; do python3 bench.py --config $c --no-cpu-baseline --no-host-paths > $O/bench_$c.json 2>/dev/null; cut -c1-200 $O/bench_$c.json; done
+  # the driver's own command line (a 20-step burst = 0.3 ms timed region)
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_line.json 2>/dev/null; cut -c1-200 $O/bench_driver_line.json ;;
 events)
   python3 $R/scratch/event_timing_probe.py > $O/event_timing_probe.txt 2>&1; cat $O/event_timing_probe.txt
   echo "label,kernel,workgroups,workgroup_size,queue,launches,mean_us,median_us,min_us,max_us" > $O/event_probe_rocprof.csv
