@@ -14,7 +14,11 @@ sizes = [int(s) for s in (sys.argv[1] if len(sys.argv) > 1 else "8,16,24,32,48,6
 x = (np.random.default_rng(0).standard_normal((max(sizes), N)) + 0j).astype(np.complex64)
 feq = np.ones_like(x)
 out = np.empty_like(x)
-print("build", g.build_id(), "pipeline", g.get_host_pipeline())
+REG = bool(os.environ.get("SWEEP_REGISTERED"))          # page-aligned, registered buffers: the kernels run on the caller's memory
+if REG:
+    x, feq, out = g.aligned_copy(x), g.aligned_copy(feq), g.aligned_empty(x.shape)
+    for arr in (x, feq, out): g.register_host(arr)
+print("build", g.build_id(), "pipeline", g.get_host_pipeline(), "registered buffers" if REG else "pageable buffers")
 def med(call, n=200):
     for _ in range(5): call()
     ts = []
