@@ -18,7 +18,8 @@ checksum (all-reduced, so the N = 1 and N = 8 runs of a strong-scaled config can
 One STEP = one pass of the hot path over one batch that is already resident in HBM.  Steps rotate through a ring of distinct
 device buffers so that consecutive steps cannot be served from the 256 MiB Infinity Cache.  W warm-up steps, then exactly K
 timed steps bracketed by barrier + synchronize on both sides; the time is the MAX over ranks; `value` = all blocks all ranks
-processed / that time.
+processed / that time.  (The garbage collector runs BEFORE the warm-up steps and is off until the timed steps are over: a collection between warm-up and timed
+steps left the GPU idle for tens of milliseconds in front of a region that is 0.3 ms long at the driver's --steps 20; GFDM_BENCH_EARLY_GC=0 restores the old order for A/B.)
 
 Beside the headline the JSON line carries
   roofline        achieved HBM GB/s of the step's dominant (slowest) kernel = algorithmic bytes per launch (16 B/symbol,
