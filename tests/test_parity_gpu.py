@@ -472,7 +472,8 @@ def test_ic_with_complex_asymmetric_taps_uses_general_convolution():
 
 
 @pytest.mark.parametrize("M,K,L,alpha", [(9, 64, 2, 0.2), (15, 128, 4, 0.2), (5, 32, 2, 0.5), (15, 64, 2, 0.2), (9, 128, 2, 0.2), (16, 256, 2, 0.3),
-                                         (4, 16, 3, 0.4), (8, 32, 2, 0.3), (12, 16, 2, 0.35), (7, 512, 2, 0.3)])
+                                         (4, 16, 3, 0.4), (8, 32, 2, 0.3), (12, 16, 2, 0.35), (7, 512, 2, 0.3),
+                                         (5, 16, 2, 0.4), (10, 128, 2, 0.3)])      # (the tile padding of the crossings: none for an odd M at K = 16; an even M at four groups)
 def test_ic_rounds_on_the_matrix_cores_match_the_vector_alu(M, K, L, alpha):
     """QPSK decisions + a real even IC kernel run the cancellation rounds as f16 MFMAs (IcMfma, gfdm_rowlane_impl.h: decisions exact in
     f16, IC taps as a two-term f16 split); handles created under set_ic_matrix_cores(False) run the same rounds on the vector ALU in
