@@ -71,7 +71,7 @@ b = s.index('## 7. Where the time goes')
 new = '''Headline (`bench.py`, configs[1], step = modulate + MF demodulate of 4096 blocks, `profiles/r04/bench_default.json`): **%.0f M blocks/s** in the 200-step burst with the
 independent steps pipelined over %d HIP streams (three or four sustain the same rate, three start a burst 3 %% faster: `profiles/r04/bench_streams_sweep.txt`) -- the demodulator
 of a step works on the frames modulated %d steps EARLIER (%.0f MB of other traffic in between, more than the 256 MiB Infinity Cache; every step is still one modulate + one demodulate of a whole batch); demodulating the frames the same step has just written gives %.0f M, i.e. the
-cache makes no measurable difference -- , **%.0f M blocks/s = %.0f GSym/s sustained over 1.9 s**, %.0f M on one stream (the boxes of the pool: 280-289 / 292-301 M).  CPU beside it
+cache makes no measurable difference -- , **%.0f M blocks/s = %.0f GSym/s sustained over 1.9 s**, %.0f M on one stream (the boxes of the pool: 278-293 / 292-307 M).  CPU beside it
 (same box, plain-C port of the reference algorithm, one kernel object per pinned pthread, set-up not timed, `oracle/gfdm_oracle_bench.c`): **%.2f M blocks/s on 16 threads** -- the
 process sees 256 logical CPUs of 2 x EPYC 9575F in its affinity mask but its cgroup grants 16 CPUs' worth of run time (`cpu.max`); `bench.py` reads the quota, runs that many threads
 and reports `cores`, `cgroup_cpu_quota`, `scaling_vs_single_thread`.  The other configurations (`bench.py --config`, burst / sustained): cfg3 %.0f / %.0f M blocks/s -- the north-star
