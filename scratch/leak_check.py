@@ -16,6 +16,13 @@ def once(i):
     adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, qpsk)
     d = qpsk[rng.integers(0, 4, (3, M * K))]
     x = mod.modulate(d); y = dem.demodulate(x); z = adv.demodulate(x)
+    if i % 4 == 0:                           # a chunked host call (staging sets, second stream, copy pool) and a registered one: HostPipe's resources go with the handle
+        big = np.tile(x, (200, 1))
+        yb = dem.demodulate(big)
+        a = gfdm_amd.aligned_copy(big); o = gfdm_amd.aligned_empty(big.shape)
+        with gfdm_amd.registered_host(a, o):
+            dem.demodulate(a, out=o)
+        assert np.array_equal(yb, o)
     est = gfdm_amd.ChannelEstimator(M, K, (K - 4) & ~1, True, 1, np.tile(np.fft.ifft(np.exp(2j * np.pi * rng.random(K))) * np.sqrt(K), 2)) if K >= 16 else None
     del mod, dem, adv, est
 for i in range(10): once(i)
