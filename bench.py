@@ -24,12 +24,16 @@ steps left the GPU idle for tens of milliseconds in front of a region that is 0.
 Beside the headline the JSON line carries
   roofline        achieved HBM GB/s of the step's dominant (slowest) kernel = algorithmic bytes per launch (16 B/symbol,
                   24 B/symbol with the per-block equaliser vector) / its duration, measured with HIP events on
-                  the launch stream: `kernel_ms` (and `achieved`, `frac`) = MEDIAN of event pairs around SINGLE launches (the form
-                  that agrees with rocprofv3's kernel duration); `kernel_ms_pipelined` = one event pair around the back-to-back run
-                  of the timed steps' launches (consecutive launches overlap head and tail: a loop property, not a kernel property);
-                  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary of the newest profiles/rNN/ -- only when
-                  that summary was measured with THIS build of the library (gfdm_hip_build_id), else null + `traffic_note`;
-                  `copy_ceiling_GBps` = a plain device copy of the same byte count, single launches timed the same way
+                  the launch stream.  Four readings of the duration, all in the object:
+                    kernel_ms (-> achieved, frac)   MEDIAN of event pairs around SINGLE launches (a pair costs 1-2 us itself)
+                    kernel_ms_pipelined             one event pair around the back-to-back run of the timed steps' launches (a burst after idle)
+                    kernel_ms_sustained             back to back for --kernel-seconds after a warm-up run: the steady state
+                    kernel_ms_rocprofv3             mean kernel duration of the committed rocprofv3 --kernel-trace collection
+                                                    (profiles/rNN/kernel_alone.csv) -- only when it was collected with THIS build
+                                                    (gfdm_hip_build_id), else null + rocprofv3_note
+                  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC summary of the newest profiles/rNN/, same build rule
+                  (else null + `traffic_note`); `copy_ceiling_GBps` = a plain device copy of the same byte count, single launches timed
+                  the same way; `north_star` (cfg2 / cfg3 runs at N = 1) = the same four readings for the ZF + 2 IC kernel of BASELINE configs[2]
   roofline_kernels  the same figures for every kernel of the step (cfg2: modulate and demodulate)
   sustained       the headline loop again for >= 2 s (the default 200 steps are a ~4 ms burst; boxes boost for short bursts)
   single_block_host_us   one generic_work(out, in) with HOST pointers through the pybind11 drop-in class (host copy into the pinned
@@ -37,7 +41,10 @@ Beside the headline the JSON line carries
   cpu_baseline    the plain-C oracle ("port" of the reference algorithm) on this host: pinned pthreads, one kernel object per
                   thread (oracle/gfdm_oracle_bench.c), all CPUs this process may run on; single thread beside it
   paths / large_batch   (N = 1, cfg2 / cfg3 only) every receiver variant and the modulator alone on the stream, and the same
-                  kernels at 65 536 blocks per launch
+                  kernels at 65 536 blocks per launch (steady state over >= 1 s, per-launch median, the burst after idle, rocprofv3)
+  rank_wall_ms / rank_hosts_cpus   (with a process group) every rank's own time for its K steps and where it ran: each rank takes a
+                  slice of the allowed CPUs by LOCAL_RANK before torch is imported and pins its launch thread to the slice's first CPU
+                  (--no-pin turns that off)
   paths.host_batch_{modulate,demod_mf,zf_ic2}   the *_host entry points -- what gr-gfdm's GNU Radio wrappers call, HOST pointers --
                   at 1 / 16 / 256 / 4096 / 65 536 blocks per call: blocks/s and bytes over the PCIe link per second, on pageable
                   memory (bounced through the pinned staging sets) and on memory registered with gfdm_hip_register_host (used in
@@ -95,6 +102,7 @@ def parse(argv=None):
                     help="HIP streams the independent steps of the headline loop are pipelined over (3 and 4 sustain the same rate, 3 starts a burst 3 %% faster: profiles/r04/bench_streams_sweep.txt)")
     ap.add_argument("--large-batch", type=int, default=65536, help="blocks per launch of the extra large-batch measurement (0 = skip)")
     ap.add_argument("--sustained-seconds", type=float, default=2.0, help="length of the sustained run of the headline loop (0 = skip)")
+    ap.add_argument("--kernel-seconds", type=float, default=0.5, help="length of the back-to-back run behind every kernel's steady-state duration (roofline.kernel_ms_sustained; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the per-variant measurements")
     ap.add_argument("--no-host-paths", action="store_true", help="skip the host-buffer (*_host entry points) measurements")
@@ -105,6 +113,7 @@ def parse(argv=None):
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N > 1 run (nccl = RCCL over xGMI; gloo lets several ranks share ONE GPU, "
                          "which is how the whole N > 1 path is exercised on a single-GPU box: every rank then uses device LOCAL_RANK %% device count)")
+    ap.add_argument("--no-pin", action="store_true", help="N > 1: do not give every rank a CPU slice of its own / pin its launch thread")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="no GPU, no GFDM compute: run launcher + rendezvous (gloo) + shard plan + synthetic-input checksum all-reduce "
                          "and print them (tests/test_bench_launcher.py)")
@@ -157,7 +166,23 @@ def slot_block_start(plan, rank, slot):
     return slot * total + start if scaling == "strong" else (rank * 1000003 + slot) * B
 
 
-def selftest_launch(a, cfg, rank, world):
+def gather_ranks(obj, world):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (outside any timed region)"""
+    import torch.distributed as dist
+    if world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def rank_placement(cpu_slice, launch_cpu):
+    """where this rank runs: host name, CPUs of its slice (count, first, last), the CPU its launch thread is pinned to"""
+    return {"host": socket.gethostname(), "cpus": len(cpu_slice) if cpu_slice else None,
+            "cpu_first": cpu_slice[0] if cpu_slice else None, "cpu_last": cpu_slice[-1] if cpu_slice else None, "launch_cpu": launch_cpu}
+
+
+def selftest_launch(a, cfg, rank, world, cpu_slice=None):
     """Launcher / rendezvous / shard plan / stat reduction without a GPU: the ranks generate the synthetic symbols of their
     shard of slot 0 on the CPU (integer hashing, no GFDM arithmetic) and all-reduce their checksum."""
     import torch
@@ -175,9 +200,12 @@ def selftest_launch(a, cfg, rank, world):
         dist.all_gather_object(ranges, (slot_block_start(plan, rank, 0), B))
     else:
         ranges = [(slot_block_start(plan, rank, 0), B)]
+    placement = gather_ranks(rank_placement(cpu_slice, pin_launch_thread(cpu_slice)), world)
+    walls = gather_ranks(1.0 * (rank + 1), world)
     if rank == 0:
         print(json.dumps({"selftest": True, "config": a.config, "n_gpus": world, "scaling": scaling, "blocks_per_step": nblocks,
-                          "shards": ranges, "input_checksum": [float(v) for v in chk], "max_elapsed": tmax}))
+                          "shards": ranges, "input_checksum": [float(v) for v in chk], "max_elapsed": tmax,
+                          "rank_wall_ms": walls, "rank_hosts_cpus": placement}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -194,7 +222,7 @@ def raw_launcher(fn, handle, out_t, in_ts, nblocks, stream_ptr):
     return go
 
 
-def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
+def timed_loop(step_fns, steps, warmup, world, time_kernels=True, kernel_seconds=0.0):
     """Run warmup + `steps` timed steps.  step_fns[i] is the list of launch closures of ring slot i (each closure is bound
     to its stream).  With `time_kernels` (single-stream loops only) every kernel of the step is then replayed alone over the same
     ring slots with ONE HIP event pair on the launch stream around the back-to-back run of its `steps` launches, i.e. the
@@ -202,7 +230,9 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
     around every single launch would add another ~2.6 us of event packets to each).
     Each kernel is also timed launch by launch, every launch inside its own event pair (single_launch_ms): the median of those pairs
     is the kernel's own duration.
-    Returns (wall seconds of the timed region, [pipelined mean in ms of kernel j of a step] or None, [single-launch median] or None)."""
+    With `kernel_seconds` > 0 each kernel is finally run back to back for that long (sustained_launch_ms): its steady-state duration.
+    Returns (wall seconds of the timed region, [pipelined mean in ms of kernel j of a step] or None, [single-launch median] or None,
+    [sustained mean] or None)."""
     import torch
     import torch.distributed as dist
     nslots = len(step_fns)
@@ -232,8 +262,8 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
         dist.barrier()                        # closing bracket: every rank has finished before anyone moves on
     torch.cuda.synchronize()
     if not time_kernels:
-        return wall, None, None
-    kern_ms, kern_single = [], []
+        return wall, None, None, None
+    kern_ms, kern_single, kern_sus = [], [], []
     for j in range(len(step_fns[0])):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(min(warmup, 4)):
@@ -245,7 +275,8 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True):
         torch.cuda.synchronize()
         kern_ms.append(e0.elapsed_time(e1) / steps)
         kern_single.append(single_launch_ms(lambda i: step_fns[(warmup + i) % nslots][j](), min(steps, 200)))
-    return wall, kern_ms, kern_single
+        kern_sus.append(sustained_launch_ms(lambda i: step_fns[i % nslots][j](), kernel_seconds, kern_single[-1])[0] if kernel_seconds > 0 else None)
+    return wall, kern_ms, kern_single, kern_sus
 
 
 def single_launch_ms(launch, n):
@@ -264,6 +295,25 @@ def single_launch_ms(launch, n):
     torch.cuda.synchronize()
     times = sorted(x.elapsed_time(y) for x, y in evs)
     return times[len(times) // 2]
+
+
+def sustained_launch_ms(launch, seconds, est_ms):
+    """STEADY-STATE duration of one kernel: `launch(i)` back to back on the current stream for about `seconds` after a warm-up run of a
+    quarter of that, one HIP event pair around the whole run -> (mean ms per launch, launches).  The first milliseconds after the GPU has been
+    idle -- a synchronize, host-side set-up -- run at another clock state: bursts of 10 launches of one kernel read up to 35 % apart on the
+    same box, while this figure and the per-launch event pairs of an equally long run agree within 2 % and repeat within 1 %
+    (profiles/r05/sustained_vs_burst.txt)."""
+    import torch
+    n = max(10, int(seconds / max(est_ms * 1e-3, 1e-7)))
+    for i in range(max(5, n // 4)):
+        launch(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n):
+        launch(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n, n
 
 
 def copy_ceiling(nbytes_moved, steps, ring_mib, dev):
@@ -305,6 +355,60 @@ def pmc_traffic(kernel_template, batch, build_id=None):
         if fetch is not None and write is not None:
             return {"bytes": (2.0 * fetch + write) * 1024.0, "source": os.path.relpath(path, ROOT)}
     return {"bytes": None, "note": note}
+
+
+def rocprof_kernel_ms(kernel_template, batch, build_id=None):
+    """mean duration (ms) of `kernel_template` at `batch` blocks per launch from the newest committed rocprofv3 --kernel-trace collection
+    (profiles/rNN/kernel_alone.csv: one kernel on the GPU at a time, rows `<K>_<M>_<L>_<path>_<batch>`), only when that collection was made
+    with THIS build of the library (profiles/rNN/build_id.txt).  Returns {"ms", "source"} or {"ms": None, "note": why}."""
+    note = "no committed rocprofv3 collection has a row for this kernel and batch"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "kernel_alone.csv")), reverse=True):
+        try:
+            their = open(os.path.join(os.path.dirname(path), "build_id.txt")).read().strip()
+        except OSError:
+            their = None
+        try:
+            for row in csv.DictReader(open(path)):
+                if row["kernel"].replace(" ", "") != kernel_template.replace(" ", "") or not row["label"].endswith("_%d" % batch):
+                    continue
+                if build_id is not None and their != build_id:
+                    note = "%s was collected with build %s, the loaded library is build %s" % (os.path.relpath(path, ROOT), their or "(not recorded)", build_id)
+                    break
+                return {"ms": float(row["mean_us"]) * 1e-3, "source": os.path.relpath(path, ROOT)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return {"ms": None, "note": note}
+
+
+def pin_rank(local_rank, local_world):
+    """Give this rank a slice of its own of the CPUs the process may run on (by LOCAL_RANK), BEFORE torch is imported so that every
+    thread a library starts later inherits it: on a multi-GPU node the ranks' launch loops, JIT and copy threads then do not migrate
+    over each other's cores.  Returns the slice (sorted CPU list); the launch thread itself is pinned to the slice's first CPU by
+    pin_launch_thread() once the set-up is over.  No-op where the platform has no affinity calls or there are fewer CPUs than ranks."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    per = len(cpus) // max(1, local_world)
+    if local_world <= 1 or per < 1:
+        return cpus
+    mine = cpus[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return cpus
+    return mine
+
+
+def pin_launch_thread(cpu_slice):
+    """the calling (launch) thread onto the first CPU of its rank's slice; threads that exist already keep the whole slice"""
+    if not cpu_slice:
+        return None
+    try:
+        os.sched_setaffinity(0, {cpu_slice[0]})
+        return cpu_slice[0]
+    except (AttributeError, OSError):
+        return None
 
 
 def allowed_cpus():
@@ -524,8 +628,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpu_slice = None if (a.no_pin or world == 1) else pin_rank(local % max(1, local_world), local_world)     # before torch is imported
     if a.selftest_launch:
-        return selftest_launch(a, cfg, rank, world)
+        return selftest_launch(a, cfg, rank, world, cpu_slice)
 
     import numpy as np
     import torch
@@ -644,8 +750,10 @@ def main():
             sb_mod.prepare(L_.gfdm_hip_modulator_work_device, [frames[s]], [(sym[s],)], [B], [stream])()
         torch.cuda.synchronize()
     piped = step_fns_on(lambda s: side[s % S].cuda_stream, lag)
+    launch_cpu = pin_launch_thread(cpu_slice)              # N > 1: the launch loop stays on one CPU of this rank's slice from here on
     wall = timed_loop(piped, a.steps, a.warmup, world, time_kernels=False)[0]
     total_blocks, _, wall_max = sharding.reduce_stats(B * a.steps, zeros3(), wall, dev)
+    rank_wall_ms = gather_ranks(wall * 1e3, world)         # every rank's own time for its K steps: a shortfall at N > 1 can be read off one run
     value = total_blocks / wall_max
     value_hot = None
     if lag:
@@ -661,7 +769,7 @@ def main():
         sus_blocks, _, wsus_max = sharding.reduce_stats(B * nsus, zeros3(), wsus, dev)
         sustained = {"seconds": wsus_max, "steps": nsus, "value": sus_blocks / wsus_max, "ms_per_step": wsus_max / nsus * 1e3}
     single = step_fns_on(lambda s: stream, lag)
-    wall1, kern_ms, kern_single = timed_loop(single, a.steps, a.warmup, world, time_kernels=True)
+    wall1, kern_ms, kern_single, kern_sus = timed_loop(single, a.steps, a.warmup, world, time_kernels=True, kernel_seconds=a.kernel_seconds)
     _, _, wall1_max = sharding.reduce_stats(0, zeros3(), wall1, dev)
     # output checksum of ring slot 0 (strong scaling: the union over the ranks is global blocks [0, total) whatever N is)
     for f in step_fns_on(lambda s: stream, 0)[0]:
@@ -674,20 +782,25 @@ def main():
     bps = ([16] if two_kernel else []) + [rx_bps]
     rk = {}
     build_id = gfdm_amd.build_id()
-    for nm, tp, bp, ms_piped, ms in zip(names, templates, bps, kern_ms, kern_single):
+    frac_of = lambda nbytes, ms: None if not ms else nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    for nm, tp, bp, ms_piped, ms, ms_sus in zip(names, templates, bps, kern_ms, kern_single, kern_sus):
         ach = bp * N * B / (ms * 1e-3) / 1e9
         tr = pmc_traffic(tp, B, build_id)
+        rp = rocprof_kernel_ms(tp, B, build_id)
         rk[nm] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                   "traffic": tr["bytes"], "traffic_source": tr.get("source"), "traffic_note": tr.get("note"),
                   "kernel": tp, "bytes_per_launch": bp * N * B, "kernel_ms": ms, "kernel_ms_pipelined": ms_piped,
-                  "achieved_pipelined": bp * N * B / (ms_piped * 1e-3) / 1e9, "frac_pipelined": bp * N * B / (ms_piped * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                  "achieved_pipelined": bp * N * B / (ms_piped * 1e-3) / 1e9, "frac_pipelined": bp * N * B / (ms_piped * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                  "kernel_ms_sustained": ms_sus, "frac_sustained": frac_of(bp * N * B, ms_sus),
+                  "kernel_ms_rocprofv3": rp["ms"], "frac_rocprofv3": frac_of(bp * N * B, rp["ms"]), "rocprofv3_source": rp.get("source"), "rocprofv3_note": rp.get("note")}
     dominant = max(rk, key=lambda k: rk[k]["kernel_ms"])
     roofline = dict(rk[dominant])
     roofline["kernel"] = "%s (%s, %s family)" % (roofline["kernel"], dominant, dem.kernel_name())
     roofline["copy_ceiling_GBps"] = copy_ceiling(roofline["bytes_per_launch"], a.steps, a.ring_mib, dev)
-    roofline["region"] = ("kernel_ms / achieved / frac: median of HIP event pairs, one pair per single launch of this kernel over the ring slots; "
-                          "*_pipelined: one event pair around the %d timed steps' launches back to back on one stream "
-                          "(consecutive launches overlap); rocprofv3 kernel time: profiles/README.md" % a.steps)
+    roofline["region"] = ("kernel_ms / achieved / frac: median of HIP event pairs, one pair per single launch of this kernel over the ring slots (the pair itself "
+                          "costs 1-2 us); *_pipelined: one event pair around the %d timed steps' launches back to back on one stream (a burst after idle); "
+                          "*_sustained: the same back to back for %.1f s after a warm-up run = steady state; *_rocprofv3: mean kernel duration of the committed "
+                          "rocprofv3 --kernel-trace collection of THIS build (null + rocprofv3_note when the committed collection is of another build)" % (a.steps, a.kernel_seconds))
     roofline["build_id"] = build_id
     if world > 1:
         roofline["rank"] = 0
@@ -695,7 +808,9 @@ def main():
         "metric": cfg["metric"],
         "value": value, "unit": "blocks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall_max / a.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        # cfg4's cancellation rounds run as v_mfma_f32_16x16x32_f16 on exact f16 decisions and a three-term f16 split of the IC taps (33
+        # significant bits, not narrower than the reference's f32), everything else and every accumulation in f32
+        "dtype": "f32 (IC rounds: f16x3-split MFMA, f32 accumulate)" if ick == 2 else "f32", "data": "synthetic",
         "config": {"workload": "%s; %d QPSK blocks per step %s, ring of %d buffer sets, independent steps pipelined over %d HIP streams%s"
                                % (cfg["workload"], total_per_step if scaling == "strong" else B,
                                   "in total, sharded contiguously over the GPUs" if scaling == "strong" else "per GPU", ns, S,
@@ -713,6 +828,9 @@ def main():
         "kernels": {"modulate": mod.kernel_name(), "demodulate": dem.kernel_name(), "advanced": adv.kernel_name()},
         "output_checksum": [float(v) for v in chk],
     }
+    if use_dist:
+        result["rank_wall_ms"] = rank_wall_ms
+        result["rank_hosts_cpus"] = gather_ranks(rank_placement(cpu_slice, launch_cpu), world)
     del sym, frames, eqs, outs, piped, single
 
     # ---- per-variant measurements (each alone on the stream, own ring): single GPU, K=64 M=9 only ---------------------------
@@ -723,11 +841,13 @@ def main():
         def measure(name, nbuf, bytes_per_sym, make_fns):
             n_slots = slots(nbuf)
             fns, keep = make_fns(n_slots)
-            w, kms, ksingle = timed_loop(fns, a.steps, a.warmup, world)
+            w, kms, ksingle, ksus = timed_loop(fns, a.steps, a.warmup, world, kernel_seconds=a.kernel_seconds)
             gbps = bytes_per_sym * N * B / (ksingle[0] * 1e-3) / 1e9
             paths[name] = {"blocks_per_s": B * a.steps / w, "msym_per_s": B * a.steps / w * N / 1e6,
-                           "kernel_ms": ksingle[0], "kernel_ms_pipelined": kms[0], "bytes_per_launch": int(round(bytes_per_sym * N * B)), "achieved_GBps": gbps,
+                           "kernel_ms": ksingle[0], "kernel_ms_pipelined": kms[0], "kernel_ms_sustained": ksus[0],
+                           "bytes_per_launch": int(round(bytes_per_sym * N * B)), "achieved_GBps": gbps,
                            "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "frac_of_hbm_peak_pipelined": bytes_per_sym * N * B / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                           "frac_of_hbm_peak_sustained": frac_of(bytes_per_sym * N * B, ksus[0]),
                            "ring_slots": n_slots}
             del keep
 
@@ -781,8 +901,18 @@ def main():
         if not a.no_host_paths:
             paths.update(host_batch_paths(cfg, taps, [int(x) for x in a.host_sizes.split(",")], with_cpu=not a.no_cpu_baseline))
         result["paths"] = paths
+        ns_tp = "k_row_receive<%d, %d, %d, 2, 1, 1>" % (K, M, L)
+        ns_rp = rocprof_kernel_ms(ns_tp, B, build_id)
+        ns = paths["demod_zf_ic2"]
         result["north_star"] = {"path": "demod_zf_ic2 (BASELINE configs[2]: ZF demod + 2 IC iterations)",
-                                "frac_of_hbm_peak": paths["demod_zf_ic2"]["frac_of_hbm_peak"], "target": 0.40}
+                                "frac_of_hbm_peak": ns["frac_of_hbm_peak"], "target": 0.40}
+        # inside `roofline` as well (the driver's record keeps that object whole): the north-star kernel on this box, all four readings
+        result["roofline"]["north_star"] = {"kernel": ns_tp + " (BASELINE configs[2]: ZF demod + 2 IC iterations, %d blocks per launch)" % B, "target_frac": 0.40,
+                                            "bytes_per_launch": ns["bytes_per_launch"], "kernel_ms": ns["kernel_ms"], "frac": ns["frac_of_hbm_peak"],
+                                            "kernel_ms_pipelined": ns["kernel_ms_pipelined"], "frac_pipelined": ns["frac_of_hbm_peak_pipelined"],
+                                            "kernel_ms_sustained": ns["kernel_ms_sustained"], "frac_sustained": ns["frac_of_hbm_peak_sustained"],
+                                            "kernel_ms_rocprofv3": ns_rp["ms"], "frac_rocprofv3": frac_of(ns["bytes_per_launch"], ns_rp["ms"]),
+                                            "rocprofv3_source": ns_rp.get("source"), "rocprofv3_note": ns_rp.get("note")}
 
     # ---- the same kernels at the batch size of BASELINE configs[3,4] (65 536 blocks per launch): steady-state roofline --------
     if a.large_batch > 0 and want_paths:
@@ -794,25 +924,37 @@ def main():
             fr, eq = zip(*[gen_rx_inputs((1000 + sl) * BL, BL, with_eq) for sl in range(nsl)])
             o = [torch.empty(BL, N, dtype=torch.complex64, device=dev) for _ in range(nsl)]
             fns = [[raw_launcher(fn, handle, o[sl], [fr[sl], eq[sl]], BL, stream)] for sl in range(nsl)]
-            nst = max(10, a.steps // 8)
-            w, kms, _ = timed_loop(fns, nst, 3, world)
-            # beside the back-to-back mean, the median of per-launch event pairs: a sustained run of launches of this size makes some
-            # boxes of the pool drop their clocks after a few milliseconds (power cap), and idle gaps make them ramp down as well, so
-            # the two figures bracket the kernel's duration
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nst)]
-            for i in range(nst):
+            # three readings of the same kernel in one run: (1) a burst of 10 launches right after the set-up, one event pair around it -- what
+            # round 4 reported as kernel_ms; it depends on the clock state the idle gap left behind (0.54 of peak on one box, 0.73 on the next);
+            # (2) back to back for >= 1 s after a warm-up run: the steady state; (3) the median of per-launch event pairs over an equally long run.
+            # (2) and (3) agree within 2 %, and with rocprofv3's kernel duration within 3 % (profiles/r05/sustained_vs_burst.txt).
+            torch.cuda.synchronize()
+            eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eb0.record()
+            for i in range(10):
+                fns[i % nsl][0]()
+            eb1.record()
+            torch.cuda.synchronize()
+            burst_ms = eb0.elapsed_time(eb1) / 10
+            sus_ms, nsus_l = sustained_launch_ms(lambda i: fns[i % nsl][0](), 1.0, burst_ms)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nsus_l)]
+            for i in range(nsus_l):
                 evs[i][0].record()
                 fns[i % nsl][0]()
                 evs[i][1].record()
             torch.cuda.synchronize()
             per_launch = sorted(x.elapsed_time(y) for x, y in evs)
             kms_med = float(np.median(per_launch))
-            gbps = bps_ * N * BL / (kms[0] * 1e-3) / 1e9
-            large[name] = {"blocks_per_launch": BL, "blocks_per_s": BL * nst / w, "kernel_ms": kms[0],
-                           "kernel_ms_per_launch_median": kms_med, "kernel_ms_per_launch_min": per_launch[0], "kernel_ms_per_launch_max": per_launch[-1],
-                           "frac_of_hbm_peak_range": [bps_ * N * BL / (per_launch[-1] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                                      bps_ * N * BL / (per_launch[0] * 1e-3) / 1e9 / HBM_PEAK_GBPS],
-                           "bytes_per_launch": bps_ * N * BL, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS}
+            tp = "k_row_receive<%d, %d, %d, %d, %d, %d>" % (K, M, L, 2 if with_eq else 1, 1 if with_eq else 0, 1 if with_eq else 0)
+            rp = rocprof_kernel_ms(tp, BL, build_id)
+            nbytes = bps_ * N * BL
+            large[name] = {"blocks_per_launch": BL, "kernel": tp, "bytes_per_launch": nbytes, "blocks_per_s": BL / (sus_ms * 1e-3),
+                           "kernel_ms": sus_ms, "frac_of_hbm_peak": frac_of(nbytes, sus_ms), "achieved_GBps": nbytes / (sus_ms * 1e-3) / 1e9,
+                           "launches_sustained": nsus_l,
+                           "kernel_ms_per_launch_median": kms_med, "frac_of_hbm_peak_per_launch_median": frac_of(nbytes, kms_med),
+                           "kernel_ms_per_launch_p10_p90": [per_launch[len(per_launch) // 10], per_launch[(9 * len(per_launch)) // 10]],
+                           "kernel_ms_burst_after_idle": burst_ms, "frac_of_hbm_peak_burst_after_idle": frac_of(nbytes, burst_ms),
+                           "kernel_ms_rocprofv3": rp["ms"], "frac_of_hbm_peak_rocprofv3": frac_of(nbytes, rp["ms"]), "rocprofv3_note": rp.get("note")}
             del fr, eq, o, fns
         result["large_batch"] = large
 

@@ -7,6 +7,7 @@
 #include "gfdm_tx.h"
 #include "gfdm_hostpipe.h"
 
+#include <cfloat>
 #include <cmath>
 #include <complex>
 #include <memory>
@@ -80,9 +81,15 @@ struct Plan {
     // are neither cached nor quick to compile: 0 compiling (estimated calls run on the generic family meanwhile), 1 ready, -1 failed (they stay there)
     std::shared_ptr<std::atomic<int>> jit_pre_pending;
 
+    // a *_host call cuts its batch into chunks, one launch each: the family (and the preamble-equalised kernels' availability) it starts
+    // with is the one all of its chunks run on, so that a background instantiation finishing meanwhile cannot change the rounding inside
+    // one call's output (FamilyPin below); -1 = not pinned
+    int pinned_family = -1, pinned_pre = -1;
+
     // the family to launch with right now
     int current_family()
     {
+        if (pinned_family >= 0) return pinned_family;
         if (jit_pending) {
             const int st = jit_pending->load(std::memory_order_acquire);
             if (st == 1) { family = gfdm::FAMILY_ROWLANE_JIT; kernel_name = "rowlane_jit"; }
@@ -351,6 +358,25 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
 
 int status_of(hipError_t e) { return e == hipSuccess ? GFDM_HIP_OK : fail_hip(e, "kernel launch"); }
 
+// resolves the handle's kernel family once, for the duration of one *_host call (Plan::pinned_family)
+struct FamilyPin {
+    Plan& pl;
+    explicit FamilyPin(Plan& p) : pl(p)
+    {
+        pl.pinned_family = pl.pinned_pre = -1;
+        const int f = pl.current_family();
+        int pre = 1;
+        if (pl.jit_pre_pending) {
+            if (pl.jit_pre_pending->load(std::memory_order_acquire) == 1) pl.jit_pre_pending.reset(); else pre = 0;
+        }
+        pl.pinned_family = f;
+        pl.pinned_pre = pre;
+    }
+    ~FamilyPin() { pl.pinned_family = pl.pinned_pre = -1; }
+    FamilyPin(const FamilyPin&) = delete;
+    FamilyPin& operator=(const FamilyPin&) = delete;
+};
+
 // Host-pointer path of the block entry points (gfdm_hostpipe.h): operands the GPU can address are used in place, the others bounce through
 // pinned staging sets in chunks, the kernels run across the link.  `launch(out, in0, in1, nb, stream)` enqueues the kernels of nb blocks and
 // returns a status.  Sizes are complex samples per block (frames in / demapped symbols out may differ from the block size); in1 may be read at
@@ -370,6 +396,7 @@ int run_host_sized(Plan& pl, float* out, size_t out_pb, const float* in0, size_t
     auto fn = [&](void* const* d, int64_t nb, hipStream_t s) {
         return launch(static_cast<cf*>(d[0]), static_cast<const cf*>(d[1]), nops == 3 ? static_cast<const cf*>(d[2]) : nullptr, nb, s);
     };
+    FamilyPin pin(pl);
     return pl.pipe.run(pl.stream, ops, nops, nblocks, fn);
 }
 
@@ -400,7 +427,8 @@ hipError_t rx_launch(Plan& pl, const gfdm::IcParams& ic, int mode, cf* out, cons
     const int family = pl.current_family();
     if (family == gfdm::FAMILY_ROWLANE) return gfdm::launch_rowlane_receive(pl.dp, ic, est, pl.d_twT, mode, out, in, f_eq, nblocks, s);
     bool tuned = family == gfdm::FAMILY_ROWLANE_JIT;
-    if (tuned && est && pl.jit_pre_pending) {
+    if (tuned && est && pl.pinned_pre >= 0) tuned = pl.pinned_pre == 1;
+    else if (tuned && est && pl.jit_pre_pending) {
         const int st = pl.jit_pre_pending->load(std::memory_order_acquire);
         if (st == 1) pl.jit_pre_pending.reset(); else tuned = false;       // still compiling (or failed): this estimated call runs on the generic family
     }
@@ -787,9 +815,14 @@ int gfdm_hip_advanced_receiver_create(gfdm_hip_advanced_receiver** out, int time
     if (rc != GFDM_HIP_OK) { delete a; return rc; }
 
     const cf* pts = reinterpret_cast<const cf*>(constellation_points);
+    // "is this GNU Radio's unit constellation": every component within four f32 ulps of the unit point's (points that went through a double ->
+    // float conversion or a product with 1/sqrt 2 in float land within one)
+    auto near = [](cf p, float re, float im) {
+        const float tr = 4.f * FLT_EPSILON * (std::fabs(re) > 0.f ? std::fabs(re) : 1.f), ti = 4.f * FLT_EPSILON * (std::fabs(im) > 0.f ? std::fabs(im) : 1.f);
+        return std::fabs(p.x - re) <= tr && std::fabs(p.y - im) <= ti;
+    };
     if (decision == GFDM_HIP_DECIDE_AUTO) {
-        const float s = 0.70710678118654752f, tol = 1e-6f;
-        auto near = [&](cf p, float re, float im) { return std::fabs(p.x - re) < tol && std::fabs(p.y - im) < tol; };
+        const float s = 0.70710678118654752f;
         if (n_points == 4 && near(pts[0], -s, -s) && near(pts[1], s, -s) && near(pts[2], -s, s) && near(pts[3], s, s))
             decision = GFDM_HIP_DECIDE_QPSK;
         else if (n_points == 2 && near(pts[0], -1.f, 0.f) && near(pts[1], 1.f, 0.f))
@@ -804,9 +837,9 @@ int gfdm_hip_advanced_receiver_create(gfdm_hip_advanced_receiver** out, int time
     // The sign-test kernels cancel with the unit constellations' own points (+-1/sqrt 2, +-1).  An explicit QPSK / BPSK rule over other
     // points (scaled, rotated) keeps its decision REGIONS only if it is the nearest-point rule of those points; it is then run as that, on
     // the points as given -- every kernel family reads ic.points for it, so a handle gives the same results on each of them.
+    // The rule a handle really runs is reported by gfdm_hip_advanced_receiver_decision.
     {
-        const float s = 0.70710678118654752f, tol = 1e-6f;
-        auto near = [&](cf p, float re, float im) { return std::fabs(p.x - re) < tol && std::fabs(p.y - im) < tol; };
+        const float s = 0.70710678118654752f;
         if (decision == GFDM_HIP_DECIDE_QPSK && !(near(pts[0], -s, -s) && near(pts[1], s, -s) && near(pts[2], -s, s) && near(pts[3], s, s)))
             decision = GFDM_HIP_DECIDE_NEAREST;
         if (decision == GFDM_HIP_DECIDE_BPSK && !(near(pts[0], -1.f, 0.f) && near(pts[1], 1.f, 0.f)))
@@ -861,6 +894,7 @@ int gfdm_hip_advanced_receiver_get_phase_compensation(const gfdm_hip_advanced_re
     return a ? a->ic.do_phase_compensation : GFDM_HIP_EINVAL;
 }
 const char* gfdm_hip_advanced_receiver_kernel_name(const gfdm_hip_advanced_receiver* a) { return a ? plan_kernel_name(a->plan) : ""; }
+int gfdm_hip_advanced_receiver_decision(const gfdm_hip_advanced_receiver* a) { return a ? a->ic.decision : GFDM_HIP_EINVAL; }
 
 int gfdm_hip_advanced_receiver_work_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* f_eq, int64_t nblocks,
                                            void* stream)
@@ -1122,6 +1156,7 @@ static int tx_host(gfdm_hip_transmitter* t, float* const* outs, int n_outs, size
     }
     ops[n_outs] = gfdm::HostOperand{ const_cast<float*>(in), in_elems_per_block * sizeof(cf), in_elems_per_block * sizeof(cf), false };
     auto fn = [&](void* const* d, int64_t nb, hipStream_t s) { return enqueue(d, d[n_outs], nb, s); };
+    FamilyPin pin(pl);
     return pl.pipe.run(pl.stream, ops, n_outs + 1, nblocks, fn);
 }
 

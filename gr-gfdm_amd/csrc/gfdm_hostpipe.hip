@@ -13,11 +13,23 @@
 #include <mutex>
 #include <thread>
 #include <unistd.h>
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 
 namespace gfdm {
 
 namespace {
+
+// one spin-wait step: frees the core's issue slots for its SMT sibling (which may be running a slice of the copy pool)
+inline void cpu_relax()
+{
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
 
 // how the bytes cross the link: 0 under the kernels' own accesses to host memory, 1 copy engines + device staging, 2 inputs under the
 // kernel's reads and outputs by copy engine, 3 the reverse (HostPipe::run)
@@ -64,6 +76,7 @@ constexpr size_t kStreamMinBytes = 32u << 10;
 #endif
 constexpr size_t kStreamCallBytes = GFDM_HOST_STREAM_CALL_BYTES;
 
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) void copy_streaming_avx2(char* d, const char* s, size_t n)
 {
     const size_t head = (32 - (reinterpret_cast<uintptr_t>(d) & 31)) & 31;       // stores must be 32-byte aligned
@@ -84,6 +97,10 @@ __attribute__((target("avx2"))) void copy_streaming_avx2(char* d, const char* s,
 }
 
 const bool g_have_avx2 = __builtin_cpu_supports("avx2");
+#else       // other hosts: memcpy everywhere (glibc's own non-temporal path above its threshold)
+inline void copy_streaming_avx2(char* d, const char* s, size_t n) { memcpy(d, s, n); }
+const bool g_have_avx2 = false;
+#endif
 std::atomic<int> g_streaming_copies{ 1 };       // 0: plain memcpy everywhere (A/B)
 
 inline void bounce_copy(char* d, const char* s, size_t n, bool streaming)
@@ -119,7 +136,10 @@ public:
         if (helpers > 0) {
             std::lock_guard<std::mutex> lk(mu_);
             if (!stopping_) {
-                while ((int)threads_.size() < helpers && (int)threads_.size() < 16) threads_.emplace_back([this] { loop(); });
+                // a new thread's baseline generation is read HERE, under the lock: a thread that first runs after quiesce() has bumped the
+                // generation would otherwise take the bumped value as its baseline, never see stopping_ and hang quiesce()'s join
+                const uint64_t g0 = gen_.load(std::memory_order_acquire);
+                while ((int)threads_.size() < helpers && (int)threads_.size() < 16) threads_.emplace_back([this, g0] { loop(g0); });
                 used = (int)threads_.size() < helpers ? (int)threads_.size() : helpers;
                 current_ = job;
                 wanted_ = used;
@@ -129,7 +149,7 @@ public:
         if (used) cv_.notify_all();
         job->work();
         const size_t n = job->slices.size();
-        while (job->done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+        while (job->done.load(std::memory_order_acquire) < n) cpu_relax();
         return used;
     }
     void quiesce()
@@ -158,16 +178,15 @@ private:
     int wanted_ = 0;
     bool stopping_ = false;
 
-    void loop()
+    void loop(uint64_t seen)
     {
-        uint64_t seen = gen_.load(std::memory_order_acquire);
         for (;;) {
             // chunks of one call follow each other within tens of microseconds: spin briefly before going to sleep
-            for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+            for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; ++spin) cpu_relax();
             std::shared_ptr<CopyJob> job;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                cv_.wait(lk, [&] { return stopping_ || gen_.load(std::memory_order_acquire) != seen; });
                 seen = gen_.load(std::memory_order_acquire);
                 if (stopping_) return;
                 if (wanted_ > 0) { --wanted_; job = current_; }
@@ -356,6 +375,7 @@ hipError_t HostPipe::wait_ticket(hipStream_t s, int slot, unsigned value)
             if (e == hipSuccess) return ((int)(*t - value) >= 0) ? hipSuccess : hipStreamSynchronize(s);
             if (e != hipErrorNotReady) return e;
         }
+        cpu_relax();
     }
 }
 
@@ -388,6 +408,17 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
         if (hipPointerGetAttributes(&a0, o.host) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (a0.type != hipMemoryTypeHost && a0.type != hipMemoryTypeDevice && a0.type != hipMemoryTypeManaged) continue;
         if (hipPointerGetAttributes(&a1, static_cast<char*>(o.host) + extent[i] - 1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        // device / managed memory is never bounced (a CPU copy would dereference a device address in the caller's thread): it is used in place, the
+        // caller vouching for the extent as with the *_device entry points, or refused
+        const bool dev_mem = a0.type == hipMemoryTypeDevice || a0.type == hipMemoryTypeManaged;
+        if (a0.type == hipMemoryTypeDevice && a0.device != cur_dev) return api_fail(GFDM_HIP_EINVAL, "buffer lives in the memory of another GPU");
+        if (dev_mem) {
+            if (!a0.devicePointer || a1.type != a0.type) return api_fail(GFDM_HIP_EINVAL, "device buffer: the runtime does not map the whole extent");
+            direct[i] = true;
+            host_mem[i] = false;
+            direct_dev[i] = static_cast<char*>(a0.devicePointer);
+            continue;
+        }
         if (a1.type != a0.type) continue;                             // only partly registered: bounce it
         // two registrations side by side need not be contiguous as the GPU sees them: the last byte must sit where the first one says
         if (a1.devicePointer != static_cast<char*>(a0.devicePointer) + (extent[i] - 1)) continue;
@@ -403,10 +434,9 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
             if (static_cast<char*>(a0.devicePointer) < static_cast<char*>(rbase) ||
                 static_cast<char*>(a0.devicePointer) + extent[i] > static_cast<char*>(rbase) + rsize) continue;
         }
-        if (a0.type == hipMemoryTypeDevice && a0.device != cur_dev) return api_fail(GFDM_HIP_EINVAL, "buffer lives in the memory of another GPU");
         if (!a0.devicePointer) continue;
         direct[i] = true;
-        host_mem[i] = a0.type == hipMemoryTypeHost;
+        host_mem[i] = true;
         direct_dev[i] = static_cast<char*>(a0.devicePointer);
     }
     // an output handed over in place must not overlap another in-place operand (the kernels assume distinct buffers): bounce it instead
@@ -416,7 +446,11 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
         for (int j = 0; j < nops; ++j) {
             if (j == i || !direct[j] || extent[j] == 0) continue;
             const char* b1 = static_cast<const char*>(ops[j].host);
-            if (b0 < b1 + extent[j] && b1 < b0 + extent[i]) { direct[i] = false; break; }
+            if (b0 < b1 + extent[j] && b1 < b0 + extent[i]) {
+                if (!host_mem[i]) return api_fail(GFDM_HIP_EINVAL, "a device-memory output overlaps another operand: the *_host calls need distinct device buffers");
+                direct[i] = false;
+                break;
+            }
         }
     }
     size_t per_block = 0, total_staged = 0;

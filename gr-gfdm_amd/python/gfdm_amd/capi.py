@@ -7,6 +7,7 @@ the reference's own binding; this module adds nothing numerically, it only
 forwards pointers.  There is no CPU fallback: a missing library or GPU raises.
 """
 import ctypes
+import mmap
 import os
 
 import numpy as np
@@ -95,6 +96,7 @@ def lib():
         "gfdm_hip_advanced_receiver_get_ic": (i32, [vp]),
         "gfdm_hip_advanced_receiver_set_phase_compensation": (i32, [vp, i32]),
         "gfdm_hip_advanced_receiver_get_phase_compensation": (i32, [vp]),
+        "gfdm_hip_advanced_receiver_decision": (i32, [vp]),
         "gfdm_hip_advanced_receiver_kernel_name": (cp, [vp]),
         "gfdm_hip_advanced_receiver_work_host": (i32, [vp, vp, vp, vp, i64]),
         "gfdm_hip_advanced_receiver_work_device": (i32, [vp, vp, vp, vp, i64, vp]),
@@ -324,7 +326,7 @@ class registered_host:
         return False
 
 
-PAGE = 4096
+PAGE = mmap.PAGESIZE
 
 
 def aligned_empty(shape, dtype=np.complex64):
@@ -615,7 +617,10 @@ class AdvancedReceiver(_Kernel):
     """gr::gfdm::advanced_receiver_kernel_cc (include/gfdm/advanced_receiver_kernel_cc.h:37-78) on the GPU.
 
     The reference takes a gr::digital::constellation_sptr; here the constellation is its points() array plus a
-    decision rule ('auto' picks the QPSK/BPSK sign tests when the points are those constellations)."""
+    decision rule ('auto' picks the QPSK/BPSK sign tests when the points are those constellations).  Only GNU Radio's UNIT constellations
+    -- (+-1 +-j)/sqrt 2 in the order --, +-, -+, ++ and -1, +1, every component within four float32 ulps -- take the sign tests (and the
+    matrix-core cancellation rounds); scaled or rotated points are decided by the nearest-point rule over the points as given, also when
+    'qpsk' / 'bpsk' was asked for.  decision_rule() reports the rule the handle runs."""
     _destroy = "gfdm_hip_advanced_receiver_destroy"
     _frames_prefix = "gfdm_hip_advanced_receiver_work_frames"
     _configure_frames = "gfdm_hip_advanced_receiver_configure_frames"
@@ -642,6 +647,11 @@ class AdvancedReceiver(_Kernel):
 
     def kernel_name(self):
         return lib().gfdm_hip_advanced_receiver_kernel_name(self._h).decode()
+
+    def decision_rule(self):
+        """'nearest' | 'qpsk' | 'bpsk': the rule this handle runs (gfdm_hip_advanced_receiver_decision)"""
+        code = lib().gfdm_hip_advanced_receiver_decision(self._h)
+        return {v: k for k, v in DECIDE.items() if k != "auto"}[code]
 
     def set_ic(self, ic_iter):
         _check(lib().gfdm_hip_advanced_receiver_set_ic(self._h, ic_iter))

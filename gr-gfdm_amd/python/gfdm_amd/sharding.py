@@ -129,7 +129,8 @@ class ShardedBatch:
         returned with their block range: [(first block, number of blocks, result)].  The host entry points block until their result is
         back, so every local device gets a host thread of its own (ctypes releases the GIL for the duration of the C call) -- the Python
         twin of gfdm/sharded_batch.h; the first exception of any shard is re-raised after all threads have finished.  The caller owns
-        assembling ranks' results, if it wants them at all."""
+        assembling ranks' results, if it wants them at all.  gfdm_amd.host_call_stats() is per calling thread, so each shard's statistics
+        are read on ITS thread and kept in self.last_host_call_stats (one dict per local shard that had blocks)."""
         import threading
         import numpy as np
         first = np.asarray(global_ins[0])
@@ -139,12 +140,15 @@ class ShardedBatch:
             s, n = self.shard(total, i)
             if n:
                 work.append((k, s, n, [np.asarray(g).reshape(total, -1)[s:s + n] for g in global_ins]))
-        results, errors = [None] * len(work), [None] * len(work)
+        results, errors, stats = [None] * len(work), [None] * len(work), [None] * len(work)
 
         def shard_call(j):
             k, s, n, parts = work[j]
             try:
                 results[j] = (s, n, getattr(k, method)(*parts))
+                if hasattr(k, "_h"):         # a gfdm_amd kernel object (the gloo tests use CPU stand-ins)
+                    from . import capi
+                    stats[j] = capi.host_call_stats()
             except BaseException as e:       # re-raised on the calling thread
                 errors[j] = e
 
@@ -159,6 +163,7 @@ class ShardedBatch:
         for e in errors:
             if e is not None:
                 raise e
+        self.last_host_call_stats = stats
         return results
 
     def synchronize(self):

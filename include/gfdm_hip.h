@@ -217,6 +217,10 @@ int gfdm_hip_advanced_receiver_get_ic(const gfdm_hip_advanced_receiver* a);     
 int gfdm_hip_advanced_receiver_set_phase_compensation(gfdm_hip_advanced_receiver* a, int enable);  /* .h:60-63 */
 int gfdm_hip_advanced_receiver_get_phase_compensation(const gfdm_hip_advanced_receiver* a);        /* .h:64 */
 const char* gfdm_hip_advanced_receiver_kernel_name(const gfdm_hip_advanced_receiver* a);
+/* the decision rule the handle RUNS (a gfdm_hip_decision, never AUTO): QPSK / BPSK -- the sign tests, and with a real even IC kernel the
+ * matrix-core rounds -- only for GNU Radio's unit constellations (every component within four f32 ulps of (+-1 +-j)/sqrt 2 resp. -1, +1 in
+ * that order); any other points, also when created with an explicit QPSK / BPSK, are decided by NEAREST over the points as given */
+int gfdm_hip_advanced_receiver_decision(const gfdm_hip_advanced_receiver* a);
 /* generic_work (f_eq == NULL, .cc:93-98) / generic_work_equalize (f_eq != NULL, .cc:100-107) */
 int gfdm_hip_advanced_receiver_work_host(gfdm_hip_advanced_receiver* a, float* out, const float* in, const float* f_eq, int64_t nblocks);
 int gfdm_hip_advanced_receiver_work_device(gfdm_hip_advanced_receiver* a, void* out, const void* in, const void* f_eq, int64_t nblocks, void* stream);

@@ -56,6 +56,32 @@ def test_weak_scaled_default_config_grows_with_the_ranks():
     assert two["shards"][0][1] == two["shards"][1][1] == 64 and two["shards"][0][0] != two["shards"][1][0]
 
 
+@pytest.mark.timeout(900)
+def test_eight_ranks_shard_plan_statistics_and_placement():
+    """the driver's scaling run has 8 ranks: launcher, rendezvous, shard plan, all-reduced statistics and the per-rank records
+    (rank_wall_ms, rank_hosts_cpus) for the weak config and both strong ones, with every rank on a CPU slice of its own"""
+    ncpu = len(os.sched_getaffinity(0))
+    for cfg, batch in (("cfg2", 40), ("cfg4", 1001), ("cfg5", 203)):
+        one = run_bench("--config", cfg, "--batch", str(batch))
+        eight = run_bench("--gpus", "8", "--config", cfg, "--batch", str(batch))
+        assert eight["n_gpus"] == 8 and len(eight["shards"]) == 8
+        assert eight["rank_wall_ms"] == [1.0 * (r + 1) for r in range(8)] and eight["max_elapsed"] == pytest.approx(0.008)
+        if cfg == "cfg2":
+            assert eight["scaling"] == "weak" and eight["blocks_per_step"] == 8 * batch
+            assert len({tuple(sh) for sh in eight["shards"]}) == 8 and all(sh[1] == batch for sh in eight["shards"])
+        else:
+            assert eight["scaling"] == "strong" and eight["blocks_per_step"] == batch
+            edges = [sh[0] for sh in eight["shards"]] + [batch]
+            assert edges[0] == 0 and all(edges[i] + eight["shards"][i][1] == edges[i + 1] for i in range(8))        # contiguous, complete
+            for a, b in zip(one["input_checksum"], eight["input_checksum"]):
+                assert abs(a - b) <= 1e-9 * max(1.0, abs(a))
+        place = eight["rank_hosts_cpus"]
+        assert len(place) == 8 and len({p["host"] for p in place}) == 1
+        if ncpu >= 8:                        # disjoint slices, the launch thread on the first CPU of its slice
+            assert all(p["cpus"] == ncpu // 8 and p["launch_cpu"] == p["cpu_first"] for p in place)
+            assert len({p["cpu_first"] for p in place}) == 8
+
+
 def test_bench_runs_under_an_external_torchrun_environment():
     """the driver's own launch: torchrun sets WORLD_SIZE, bench.py must then NOT start ranks of its own"""
     env = dict(os.environ, OMP_NUM_THREADS="1")
@@ -148,3 +174,36 @@ def test_whole_multi_rank_bench_path_on_one_gpu():
         for a, b in zip(res[1]["output_checksum"], res[n]["output_checksum"]):
             assert abs(a - b) <= 1e-9 * max(1.0, abs(a))
     assert all(r["value"] > 1e6 and r["roofline"]["frac"] > 0.05 for r in res.values())
+    assert len(res[3]["rank_wall_ms"]) == 3 and max(res[3]["rank_wall_ms"]) == pytest.approx(res[3]["ms_per_step"] * 3, rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("cfg,batch", [("cfg2", 256), ("cfg4", 4000), ("cfg5", 1000)])
+def test_eight_rank_bench_on_one_gpu(cfg, batch):
+    """`--gpus 8` END TO END as the driver's scaling run starts it, the eight ranks sharing the one GPU of the test box through
+    `--dist-backend gloo`: rc 0, one JSON line, eight per-rank records; the strong-scaled configs' all-reduced output checksum equals
+    the one-rank run's (same global blocks whatever the split), the weak config processes eight batches."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = {}
+    for n in (1, 8):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "gloo", "--config", cfg, "--batch", str(batch),
+                            "--steps", "3", "--warmup", "1", "--sustained-seconds", "0", "--kernel-seconds", "0.05", "--no-cpu-baseline", "--no-paths",
+                            "--ring-mib", "256"] + (["--force-dist"] if n == 1 else []), env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        res[n] = json.loads(lines[0])
+    one, eight = res[1], res[8]
+    assert eight["n_gpus"] == 8 and len(eight["rank_wall_ms"]) == 8 and len(eight["rank_hosts_cpus"]) == 8
+    assert max(eight["rank_wall_ms"]) == pytest.approx(eight["ms_per_step"] * 3, rel=1e-6)          # the line's time is the slowest rank's
+    assert eight["distributed"]["world_size"] == 8 and eight["value"] > 1e5
+    if cfg == "cfg2":
+        assert eight["scaling"] == "weak" and eight["config"]["blocks_per_step_all_gpus"] == 8 * batch and eight["config"]["batch_per_gpu"] == batch
+        assert eight["output_checksum"][2] == pytest.approx(8 * one["output_checksum"][2], rel=0.02)   # eight different batches of unit-energy symbols
+    else:
+        assert eight["scaling"] == "strong" and eight["config"]["blocks_per_step_all_gpus"] == batch and eight["config"]["batch_per_gpu"] == batch // 8
+        for a, b in zip(one["output_checksum"], eight["output_checksum"]):
+            assert abs(a - b) <= 1e-9 * max(1.0, abs(a))

@@ -476,7 +476,7 @@ def test_ic_with_complex_asymmetric_taps_uses_general_convolution():
                                          (5, 16, 2, 0.4), (10, 128, 2, 0.3)])      # (the tile padding of the crossings: none for an odd M at K = 16; an even M at four groups)
 def test_ic_rounds_on_the_matrix_cores_match_the_vector_alu(M, K, L, alpha):
     """QPSK decisions + a real even IC kernel run the cancellation rounds as f16 MFMAs (IcMfma, gfdm_rowlane_impl.h: decisions exact in
-    f16, IC taps as a two-term f16 split); handles created under set_ic_matrix_cores(False) run the same rounds on the vector ALU in
+    f16, IC taps as a three-term f16 split); handles created under set_ic_matrix_cores(False) run the same rounds on the vector ALU in
     f32.  Both must match the float64 oracle to 1e-5 (MF and ZF input, partial subcarrier maps, 1-5 rounds, plain blocks and demapped
     frames) and each other to well below that."""
     import gfdm_amd
@@ -542,6 +542,42 @@ def test_phase_compensation_removes_a_common_phase():
             check_err("phase_comp_invariance_%d_%d" % (M, K), rel_err(pc.demodulate(xr)[keep], clean[keep]), 2e-6)
             act = lambda v: v.reshape(B, K, M)[:, smap, :]
             assert abs(np.angle(np.sum(act(nopc.demodulate(xr)) * np.conj(act(nopc.demodulate(x))))) - phi0) < 0.01
+
+
+def test_duplicate_subcarrier_map_entry_counts_twice_in_the_phase_mean():
+    """Known answer for lib/advanced_receiver_kernel_cc.cc:78-91, 109-123 (no Python model, no reference test): calculate_phase_offset
+    iterates the subcarrier MAP, not the set of active subcarriers, and divides by map.size() * timeslots -- a subcarrier listed twice
+    weighs twice in the phase mean.  The measured phase is read back from the product alone: with one IC round, phase compensation turns
+    S by phi and nothing else, so out_pc - out_nopc = d0 (exp(j phi) - 1) with d0 the plain demodulator output.  Subcarriers k1 and k2
+    carry symbols turned by different angles, so phi[k1] != phi[k2], and the answers are
+        phi[k1, k2] = (phi[k1] + phi[k2]) / 2,   phi[k1, k2, k2] = phi[k2, k1, k2] = (phi[k1] + 2 phi[k2]) / 3.
+    The oracle (restated from the same lines, read against the source) is compared on the duplicated map as well."""
+    import gfdm_amd
+    for (M, K, L, alpha) in ((9, 64, 2, 0.2), (15, 128, 4, 0.2), (5, 32, 2, 0.5), (127, 16, 2, 0.3)):       # (M = 127: generic family)
+        rng = np.random.default_rng(7 * M + K)
+        taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+        nt = R.normalize_taps(taps, M)
+        N, B, k1, k2 = M * K, 4, 3, 7
+        d = np.zeros((B, K, M), complex)
+        d[:, k1, :] = qpsk(rng, (B, M)) * np.exp(-0.02j)
+        d[:, k2, :] = qpsk(rng, (B, M)) * np.exp(0.08j)
+        x = R.modulate(d.reshape(B, N), nt, M, K, L)
+        d0 = gfdm_amd.Demodulator(M, K, L, taps).demodulate(x).astype(np.complex128)
+
+        def run(smap, pc):
+            return gfdm_amd.AdvancedReceiver(M, K, L, taps, np.asarray(smap), 1, R.qpsk_points(), do_phase_compensation=pc).demodulate(x)
+
+        def phi(smap):
+            diff = run(smap, 1).astype(np.complex128) - run(smap, 0)
+            return np.angle(1.0 + np.sum(np.conj(d0) * diff, axis=-1) / np.sum(np.abs(d0) ** 2, axis=-1))
+
+        p1, p2 = phi([k1]), phi([k2])
+        assert np.min(np.abs(p1 - p2)) > 0.05                      # the two subcarriers do measure different offsets
+        assert np.max(np.abs(phi([k1, k2]) - (p1 + p2) / 2)) < 2e-5
+        assert np.max(np.abs(phi([k1, k2, k2]) - (p1 + 2 * p2) / 3)) < 2e-5
+        assert np.max(np.abs(phi([k2, k1, k2]) - (p1 + 2 * p2) / 3)) < 2e-5
+        ref = R.advanced_receive(x, nt, M, K, L, [k1, k2, k2], R.qpsk_points(), 1, do_phase_compensation=1, kind="qpsk")
+        check_err("phase_comp_duplicate_map_%d_%d" % (M, K), rel_err(run([k1, k2, k2], 1), ref), TOL)
 
 
 def test_sharded_batch_on_the_gpu():
