@@ -691,9 +691,8 @@ def main():
             n = min(GEN_CHUNK, count - c)
             x = mod.modulate(synth.qpsk_symbols(block_start + c, n, N, dev))
             if with_eq:
-                f = synth.channel_response(block_start + c, n, N, dev)
-                eq[c:c + n] = f
-                x = synth.through_channel(x, f)
+                eq[c:c + n] = synth.channel_response(block_start + c, n, N, dev)
+                x = synth.through_test_channel(x, block_start + c)      # (element-wise: the same block whatever chunk or shard generates it)
             fr[c:c + n] = x
         torch.cuda.synchronize()
         return fr, eq

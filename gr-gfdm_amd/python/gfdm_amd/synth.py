@@ -38,16 +38,53 @@ def qpsk_symbols(block_start, nblocks, block_size, device, seed=SEED, active_mas
     return out.contiguous()
 
 
+def _block_phase(block_start, nblocks):
+    """exp(0.01j b) for global blocks b, computed on the host in float64 (numpy): (cos, sin) as float32 arrays"""
+    b = np.arange(block_start, block_start + nblocks, dtype=np.float64)
+    return np.cos(0.01 * b).astype(np.float32), np.sin(0.01 * b).astype(np.float32)
+
+
+def _cmul_parts(ar, ai, br, bi):
+    """(ar + j ai)(br + j bi) from single-rounding real operations (every torch op below is ONE IEEE operation per element, so the
+    result does not depend on which code path -- vectorised, tail, fused-multiply-add contracted or not -- an element-wise kernel takes
+    for a given tensor size: a batch generated in one piece equals the same blocks generated shard by shard, bit for bit)"""
+    return ar * br - ai * bi, ar * bi + ai * br
+
+
 def channel_response(block_start, nblocks, block_size, device):
-    """Per-block one-tap equaliser input f_eq[b] = FFT_N(h) * exp(0.01j * b), complex64 (nblocks, block_size)."""
-    h = torch.zeros(block_size, dtype=torch.complex64, device=device)
-    h[:len(CHANNEL)] = torch.tensor(CHANNEL, dtype=torch.complex64, device=device)
-    H = torch.fft.fft(h)
-    b = torch.arange(block_start, block_start + nblocks, dtype=torch.float32, device=device)
-    phase = torch.polar(torch.ones_like(b), 0.01 * b)
-    return (phase[:, None] * H[None, :]).contiguous()
+    """Per-block one-tap equaliser input f_eq[b] = FFT_N(h) * exp(0.01j * b), complex64 (nblocks, block_size); block b's vector is the
+    same whatever batch it is generated in."""
+    h = np.zeros(block_size, dtype=np.complex128)
+    h[:len(CHANNEL)] = CHANNEL
+    H = np.fft.fft(h).astype(np.complex64)
+    c, s = _block_phase(block_start, nblocks)
+    Hr = torch.from_numpy(np.ascontiguousarray(H.real)).to(device)[None, :]
+    Hi = torch.from_numpy(np.ascontiguousarray(H.imag)).to(device)[None, :]
+    re, im = _cmul_parts(torch.from_numpy(c).to(device)[:, None], torch.from_numpy(s).to(device)[:, None], Hr, Hi)
+    return torch.complex(re, im).contiguous()
 
 
 def through_channel(frames, f_eq):
     """Apply the per-block circular channel to modulated frames (input preparation, not timed)."""
     return torch.fft.ifft(torch.fft.fft(frames, dim=-1) * f_eq, dim=-1).to(torch.complex64).contiguous()
+
+
+def through_test_channel(frames, block_start):
+    """The frames of global blocks [block_start, ...) through the circular test channel whose response channel_response() returns -- in the
+    TIME domain (y[n] = exp(0.01j b) * sum_t h[t] x[(n - t) mod N], four rolled multiply-adds out of single-rounding real operations), so
+    that block b's result does not depend on which batch it is generated in (a batched FFT picks its plan by the batch size, and an
+    element-wise complex multiply its code path by the tensor size; the strong-scaled bench configurations compare output checksums
+    between different splits of the same global blocks)."""
+    nblocks = frames.shape[0]
+    c, s = _block_phase(block_start, nblocks)
+    xr, xi = frames.real, frames.imag
+    out_r = torch.zeros_like(xr)
+    out_i = torch.zeros_like(xi)
+    for t, h in enumerate(CHANNEL):
+        coef = (c.astype(np.float64) + 1j * s.astype(np.float64)) * complex(h)         # per-block coefficient, rounded once to float32
+        cr = torch.from_numpy(coef.real.astype(np.float32)).to(frames.device)[:, None]
+        ci = torch.from_numpy(coef.imag.astype(np.float32)).to(frames.device)[:, None]
+        tr, ti = _cmul_parts(cr, ci, torch.roll(xr, t, dims=-1), torch.roll(xi, t, dims=-1))
+        out_r = out_r + tr
+        out_i = out_i + ti
+    return torch.complex(out_r, out_i).contiguous()

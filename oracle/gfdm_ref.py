@@ -13,24 +13,39 @@ a leading batch axis.  Each function cites the reference lines it follows
   receiver     lib/receiver_kernel_cc.cc:56-63, 99-118, 165-192, 211-225, 274-334
   IC receiver  lib/advanced_receiver_kernel_cc.cc:56-123
 
-Pinning (see DESIGN.md "Oracle"): every stage is checked against golden vectors produced in the build
-container by the reference's own Python model `pygfdm` (tests/golden/make_golden*.py, tests/test_oracle.py):
+Pinning (DESIGN.md section 2 keeps the same two lists):
+
+FIXTURE-PINNED -- checked against golden vectors produced in the build container by the reference's own Python model
+`pygfdm` (tests/golden/make_golden*.py, tests/test_oracle.py):
   * modulate (any overlap) and demodulate (overlap == 2): gfdm_modulate_block / gfdm_demodulate_block, exactly
     the expectation the reference's C++ tests use (python/qa_python_bindings.py:254-440);
+  * the receiver's filter stage at any overlap: pygfdm's overlap-generic model gfdm_demodulate_fft_loop
+    (python/pygfdm/gfdm_receiver.py:190-199; fixtures rxl_*.npz), plus the exact transpose identity with the modulator
+    (tests/test_oracle.py::test_receiver_is_transpose_of_modulator);
   * ic_filter_taps, cancel_sc_interference and the IC loop (to_td -> 5 x (QPSK decision, cancel against the
     unchanged S, to_td)): gfdm_get_ic_f_taps, gfdm_remove_sc_interference, gfdm_transform_subcarriers_to_tdomain,
     map_qpsk_stream (python/pygfdm/gfdm_receiver.py:91-114, utils.py:80-82; tests/golden/make_golden_ic.py),
-    for real RRC taps and for complex asymmetric taps, BASELINE configs 1-5 and the reference's IC test shapes;
+    for real RRC taps and for complex asymmetric taps, BASELINE configs 1-5 and the reference's IC test shapes
+    (the IC functions do not depend on the overlap once S is given, so overlap 4 is pinned too);
     plus the reference tests' own known answers (genie IC to 1 place, loop-back convergence:
     python/qa_python_bindings.py:410-415, python/qa_advanced_receiver_sb_cc.py:119,172);
-  * the receiver's filter stage at overlap != 2 has NO reference expectation (pygfdm's receiver hard-codes
-    overlap 2, python/pygfdm/gfdm_receiver.py:54,207); it is pinned through the exact transpose identity with
-    the (pinned) modulator, tests/test_oracle.py::test_receiver_is_transpose_of_modulator.  The IC stage at
-    overlap 4 IS pinned by pygfdm (its functions do not depend on the overlap once S is given);
-  * gr::digital::constellation (GNU Radio, outside the reference tree): QPSK decisions agree with pygfdm's
-    map_qpsk_stream away from exact zeros; the zero -> negative-point tie rule is from GNU Radio's source;
-  * the C++ reference itself is unbuildable here (needs FFTW3f, VOLK and GNU Radio headers, none installed)
-    and was NOT built against stand-ins.
+  * QPSK decisions (gr::digital::constellation_qpsk, GNU Radio, outside the reference tree) agree with pygfdm's
+    map_qpsk_stream away from exact zeros;
+  * transmitter chain, mapper / demapper, prefixer, preamble estimator, estimate_snr: tx_*.npz, est_*.npz, snr_*.npz.
+
+RESTATED, READ AGAINST THE SOURCE -- the C++ has no Python counterpart for these and cannot run here (it needs FFTW3f,
+VOLK and GNU Radio headers, none installed; it was NOT built against stand-ins), so no reference-generated fixture
+exists or can exist.  decide / phase_offset / advanced_receive below restate the lines; each has a known-answer test
+derived from its definition:
+  * phase compensation, lib/advanced_receiver_kernel_cc.cc:59-71, 78-91 (decision before rotation, the rotation of S
+    persists, rotator with increment 1 = one constant phase, sum of arg differences WITHOUT unwrapping):
+    tests/test_oracle.py::test_phase_compensation_removes_a_common_phase;
+  * partial subcarrier maps, :109-123 (block zeroed, only map entries decided), and the phase mean running over the
+    MAP, :82-90 -- a subcarrier listed twice weighs twice and the divisor is map.size() * timeslots:
+    tests/test_parity_gpu.py::test_duplicate_subcarrier_map_entry_counts_twice_in_the_phase_mean;
+  * the tie rule of constellation_qpsk::decision_maker, zero -> the negative point (from GNU Radio's source; called
+    at :119): tests/test_parity_gpu.py::test_all_zero_and_tie_inputs_follow_the_reference_decision_rule.
+  Every other constellation: nearest point, first minimum wins -- parity unpinned.
 
 All arithmetic is complex128; callers round to complex64 where they compare
 with float32 results.

@@ -22,12 +22,13 @@ tests)
   cd $R
   timeout 2700 python -m pytest tests -x -q -m gpu --durations=8 > $O/pytest_gpu.txt 2>&1; echo "rc=$?" >> $O/pytest_gpu.txt; tail -14 $O/pytest_gpu.txt
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
-probe)
-  for spec in "demod_zf_ic2 65536 64 9 2" "demod_mf_ic2 65536 64 9 2" "demod_mf 65536 64 9 2" "demod_zf_ic2 4096 64 9 2" \
-              "demod_mf_ic2 8192 128 15 4" "demod_mf_ic2 65536 128 15 4" "demod_zf 8192 256 31 2" "demod_zf 65536 256 31 2"; do
+probe)     # PROBE_SPECS: "path blocks K M L" entries separated by ';' (default: the kernels of VERDICT r04 weak item 4 and the 8-GPU configs)
+  specs=${PROBE_SPECS:-"demod_zf_ic2 65536 64 9 2;demod_mf_ic2 65536 64 9 2;demod_mf 65536 64 9 2;demod_zf_ic2 4096 64 9 2;demod_mf_ic2 8192 128 15 4;demod_mf_ic2 65536 128 15 4;demod_zf 8192 256 31 2;demod_zf 65536 256 31 2"}
+  IFS=';' read -ra list <<< "$specs"
+  for spec in "${list[@]}"; do
     set -- $spec
     timeout 300 python3 $R/scratch/sustained_probe.py $1 $2 $3 $4 $5 2.0 > $O/sustained_$1_$3_$4_$5_$2.txt 2>&1
-    cat $O/sustained_$1_$3_$4_$5_$2.txt
+    cut -c1-260 $O/sustained_$1_$3_$4_$5_$2.txt
   done ;;
 bench)
   cd $R
@@ -50,7 +51,7 @@ pmc)
   rm -rf $O/pmc; mkdir -p $O/pmc
   id=$(python3 -c "import sys; sys.path.insert(0, '$R/gr-gfdm_amd/python'); import gfdm_amd; print(gfdm_amd.build_id())")
   for spec in "modulate 4096 64 9 2" "demod_mf 4096 64 9 2" "demod_zf 4096 64 9 2" "demod_mf_ic2 4096 64 9 2" "demod_zf_ic2 4096 64 9 2" "demod_zf_ic2 65536 64 9 2" \
-              "demod_mf_ic2 8192 128 15 4" "demod_mf_ic2 65536 128 15 4" "demod_zf 8192 256 31 2" "demod_zf 65536 256 31 2"; do
+              "demod_mf_ic2 8192 128 15 4" "demod_mf_ic2 65536 128 15 4" "demod_zf 8192 256 31 2" "demod_zf 65536 256 31 2"}; do
     set -- $spec; run=$1_$3_$4_$5_$2; reps=40; [ $2 -ge 65536 ] && reps=12; [ $2 -ge 65536 ] && [ $3 -ge 256 ] && reps=6
     for c in FETCH_SIZE WRITE_SIZE; do
       timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc/$run/$c -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1

@@ -1,6 +1,6 @@
 """Why does one kernel read differently back to back and launch by launch?  (VERDICT r04, weak item 4 / task 2b)
 
-usage: sustained_probe.py <modulate|demod_mf|demod_zf|demod_mf_ic2|demod_zf_ic2> <blocks> [K M L] [seconds]
+usage: sustained_probe.py <copy|modulate|demod_mf|demod_zf|demod_mf_ic2|demod_zf_ic2> <blocks> [K M L] [seconds]
 
 For ONE kernel at ONE batch, in one process, on a ring of buffer sets larger than the Infinity Cache:
   burst      back-to-back runs of 10 launches inside one HIP event pair (what bench.py's large_batch `kernel_ms` was), 6 times, a
@@ -112,7 +112,9 @@ torch.cuda.synchronize()
 
 def go(i):
     x, f, o = data[i % slots]
-    if path == "modulate":
+    if path == "copy":                                 # control: a plain device copy of the same 16 N bytes per block (torch's copy kernel)
+        o.copy_(x)
+    elif path == "modulate":
         mod.modulate(x, out=o)
     elif path == "demod_mf":
         dem.demodulate(x, out=o)

@@ -135,7 +135,7 @@ def rel_err(a, b):
 
 def check_err(tag, err, tol):
     """assert err < tol; with GFDM_ERRLOG=<file> the measured error is also appended there ("tag err tol"), which is where the per-path
-    error table of DESIGN.md section 2 comes from (scratch/errlog_table.py)."""
+    error table profiles/r03/parity_error_table.md comes from (scratch/errlog_table.py)."""
     log = os.environ.get("GFDM_ERRLOG")
     if log:
         with open(log, "a") as f:
