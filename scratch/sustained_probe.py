@@ -136,11 +136,11 @@ _probe_buf = torch.zeros(4096, 2, dtype=torch.int64, device=dev)
 _probe_n = [0]
 
 
-def probe():
-    """queue a clock probe; returns its index"""
+def probe(ticks=2000):
+    """queue a clock probe of `ticks` x 10 ns; returns its index"""
     i = _probe_n[0]
     _probe_n[0] += 1
-    assert _pl.sclk_probe(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(_probe_buf[i].data_ptr()), 2000) == 0
+    assert _pl.sclk_probe(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(_probe_buf[i].data_ptr()), ticks) == 0
     return i
 
 
@@ -179,13 +179,17 @@ for rep in range(6):
 for rep in range(6):
     t0 = time.perf_counter()
     pairs = [(ev(), ev()) for _ in range(n)]
+    clk = []
     for i in range(n):
         pairs[i][0].record()
         go(rep * n + i)
         pairs[i][1].record()
+        clk.append(probe(300))                         # 3 us of the shader clock right behind every launch
     torch.cuda.synchronize()
-    t = sorted(x.elapsed_time(y) for x, y in pairs)
+    ts = [x.elapsed_time(y) for x, y in pairs]
+    t = sorted(ts)
     print("pairs %d     %d launches, a pair each: median %.4f ms (min %.4f max %.4f)  frac %.3f | %s" % (rep, n, t[n // 2], t[0], t[-1], frac(t[n // 2]), smp.window(t0, time.perf_counter())))
+    print("            launch by launch, ms @ shader MHz behind it: " + "  ".join("%.4f@%.0f" % (a, mhz(c)) for a, c in zip(ts, clk)))
 
 # sustained back to back
 est = ms * 1e-3
