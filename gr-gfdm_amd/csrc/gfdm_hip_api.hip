@@ -288,6 +288,17 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
         tables.insert(tables.end(), packed, packed + A.size() / 2);
     }
 
+    // Rader transforms for prime timeslot counts above the register codelets (gfdm_rader.hip): the kernel spectrum, default mode only
+    size_t rader_off = 0;
+    if (g_dft_mfma.load() == 1 && !g_force_generic.load() && gfdm::rader_supports(M, K)) {
+        std::vector<cf> rtab;
+        gfdm::rader_host_table(M, rtab);
+        if (!rtab.empty()) {
+            rader_off = tables.size();
+            tables.insert(tables.end(), rtab.begin(), rtab.end());
+        }
+    }
+
     DeviceGuard guard(device);
     if (!guard.ok) return fail(GFDM_HIP_ENODEV, "hipSetDevice failed");
     HIP_TRY(hipMalloc(&pl.d_tables, tables.size() * sizeof(cf)));
@@ -314,6 +325,7 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
     dp.dft_mt = dft_mt;
     dp.dft_ks = dft_ks;
     dp.dft_always = g_dft_mfma.load() == 2 ? 1 : 0;
+    dp.raderB = rader_off ? pl.d_tables + rader_off : nullptr;
     // kernel family: row-lane where the shape is instantiated, else the generic LDS family.  Only the explicit test hook
     // gfdm_hip_force_generic_family_for_testing changes that; no environment variable does.
     pl.family = gfdm::FAMILY_GENERIC;
@@ -349,7 +361,8 @@ int plan_create(Plan& pl, int M, int K, int L, const float* taps, int ntaps, int
             }
         }
     }
-    pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : pl.family == gfdm::FAMILY_ROWLANE_JIT ? "rowlane_jit" : "generic_lds";
+    pl.kernel_name = pl.family == gfdm::FAMILY_ROWLANE ? "rowlane" : pl.family == gfdm::FAMILY_ROWLANE_JIT ? "rowlane_jit" :
+                     dp.raderB ? "generic_rader" : "generic_lds";       // generic_rader: plain blocks on the Rader kernels (gfdm_rader.hip), the rest generic
     // the generic family holds two tiles of the block in LDS; handles on the row-lane families only use it for the stand-alone
     // transform_subcarriers_to_td / cancel_sc_interference entry points (one tile)
     if (!gfdm::generic_supports(M, K, pl.family != gfdm::FAMILY_GENERIC)) return fail(GFDM_HIP_EUNSUPPORTED, "root tables (2 * timeslots + subcarriers values) do not fit LDS");

@@ -37,6 +37,9 @@ struct DevicePlan {
     const float* dftA;
     int dft_mt, dft_ks;
     int dft_always;     // 1: wherever the operand scratch fits LDS (gfdm_hip_set_dft_matrix_cores(2)), 0: only where that form is the faster one
+    // prime timeslot counts served by Rader transforms (gfdm_rader.hip): FFT_{M-1}(b) / (M - 1) of the convolution kernel b[p] = W_M^(g^-p), in the
+    // order the kernels read it; nullptr = dense transforms (generic kernels)
+    const cf* raderB;
 };
 
 // Where the receiver finds its samples and how it emits its symbols: the cyclic-prefix removal
@@ -95,6 +98,12 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const
 hipError_t launch_generic_to_td(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
 hipError_t launch_generic_cancel(const DevicePlan& p, cf* out, const cf* td, const cf* fd, int64_t nblocks, hipStream_t s);
 bool generic_supports(int M, int K, bool one_tile);
+// ---- Rader transforms for prime timeslot counts above the register codelets (gfdm_rader.hip; plain blocks only, the generic launchers fall through to them) ----
+bool rader_supports(int M, int K);
+bool rader_applies_modulate(const DevicePlan& p, const TxParams& tx);
+bool rader_applies_receive(const DevicePlan& p, const IcParams& ic, const EstPlan* est, int mode);
+hipError_t launch_rader_modulate(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
+hipError_t launch_rader_receive(const DevicePlan& p, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks, hipStream_t s);
 
 // ---- row-lane family (gfdm_rowlane_impl.h, dispatch in gfdm_rowlane.hip): one lane per subcarrier row, in-place radix-4 passes ----
 bool rowlane_supports(int M, int K, int L);
@@ -109,7 +118,9 @@ hipError_t launch_rowlane_receive(const DevicePlan& p, const IcParams& ic, const
 #include <atomic>
 #include <memory>
 #include <string>
+#include <vector>
 namespace gfdm {
+void rader_host_table(int M, std::vector<cf>& tab);          // empty when the timeslot count has no Rader kernels
 struct JitCache {
     std::atomic<const void*> part[5];
     JitCache() { for (auto& p : part) p.store(nullptr); }

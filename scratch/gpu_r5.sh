@@ -12,7 +12,7 @@ trace() {   # trace <out.csv> <label> <min launches> <run_kernel args...>
   local out=$1 label=$2 minl=$3; shift 3
   rm -rf /tmp/alone/$label
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/alone/$label -o t -- python3 $R/scratch/run_kernel.py "$@" > /dev/null 2>&1
-  python3 $R/scratch/trace_by_shape.py /tmp/alone/$label/t_kernel_trace.csv | grep -E "k_row|k_est|k_generic" | awk -v l=$label -v r=$minl -F'"' '{split($3,a,","); if (a[5]+0 >= r) print l "," "\"" $2 "\"" $3}' >> $out
+  python3 $R/scratch/trace_by_shape.py /tmp/alone/$label/t_kernel_trace.csv | grep -E "k_row|k_est|k_generic|k_rader" | awk -v l=$label -v r=$minl -F'"' '{split($3,a,","); if (a[5]+0 >= r) print l "," "\"" $2 "\"" $3}' >> $out
 }
 case $1 in
 newtests)
@@ -45,6 +45,11 @@ alone)
   for b in 8192 65536; do
     for p in demod_mf demod_mf_ic2 demod_zf_ic2; do trace $O/kernel_alone.csv 128_15_4_${p}_$b 20 $p $b 40 2 128 15 4; done
     for p in demod_mf demod_zf modulate; do trace $O/kernel_alone.csv 256_31_2_${p}_$b 10 $p $b 20 2 256 31 2; done
+  done
+  for b in 4096 65536; do   # the reference's QA shape (127 timeslots, 16 subcarriers): Rader kernels, and the dense matrix-core form beside them (GFDM_DFT_MX=2)
+    reps=100; slots=12; [ $b = 65536 ] && { reps=20; slots=2; }
+    for p in modulate demod_mf demod_zf; do trace $O/kernel_alone.csv 16_127_2_${p}_$b $((reps / 2)) $p $b $reps $slots 16 127 2; done
+    for p in modulate demod_mf demod_zf; do GFDM_DFT_MX=2 trace $O/kernel_alone.csv 16_127_2_dense_${p}_$b $((reps / 2)) $p $b $reps $slots 16 127 2; done
   done
   cat $O/kernel_alone.csv | cut -d, -f1-2,8- ;;
 pmc)

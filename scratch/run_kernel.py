@@ -10,6 +10,7 @@ path = sys.argv[1]; B = int(sys.argv[2]); reps = int(sys.argv[3]); slots = int(s
 K, M, L = (int(x) for x in (sys.argv[5], sys.argv[6], sys.argv[7])) if len(sys.argv) > 7 else (64, 9, 2)
 N = K * M
 dev = torch.device("cuda:0")
+if os.environ.get("GFDM_DFT_MX"): gfdm_amd.set_dft_matrix_cores(int(os.environ["GFDM_DFT_MX"]))   # A/B: 2 = dense matrix-core timeslot transforms also where Rader kernels exist
 if os.environ.get("GFDM_MX"): gfdm_amd.set_ic_matrix_cores(int(os.environ["GFDM_MX"]))      # A/B: 0 IC rounds on the vector ALU, 2 matrix cores everywhere
 taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
 mod = gfdm_amd.Modulator(M, K, L, taps); dem = gfdm_amd.Demodulator(M, K, L, taps)

@@ -413,8 +413,10 @@ def test_baseline_shapes_run_on_the_tuned_family():
         assert gfdm_amd.Modulator(M, K, L, taps).kernel_name() == "rowlane"
         assert gfdm_amd.Demodulator(M, K, L, taps).kernel_name() == "rowlane"
         assert gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, R.qpsk_points()).kernel_name() == "rowlane"
-    taps = get_frequency_domain_filter("rrc", 0.35, 127, 16, 2)                  # M > 48: no register codelet
-    assert gfdm_amd.Demodulator(127, 16, 2, taps).kernel_name() == "generic_lds"
+    taps = get_frequency_domain_filter("rrc", 0.35, 127, 16, 2)                  # M > 48: no register codelet; the reference's QA shape: Rader transforms
+    assert gfdm_amd.Demodulator(127, 16, 2, taps).kernel_name() == "generic_rader"
+    taps = get_frequency_domain_filter("rrc", 0.35, 113, 16, 2)
+    assert gfdm_amd.Demodulator(113, 16, 2, taps).kernel_name() == "generic_lds"
     taps = get_frequency_domain_filter("rrc", 0.35, 9, 74, 2)                    # K = 2 x 37: a prime factor above 32, no butterfly codelet
     assert gfdm_amd.Demodulator(9, 74, 2, taps).kernel_name() == "generic_lds"
 
@@ -451,6 +453,60 @@ def test_generic_family_on_the_tuned_shapes(M, K, L, alpha):
         g = gadv.demodulate(inp) if eq is None else gadv.demodulate_equalize(inp, eq)
         r = radv.demodulate(inp) if eq is None else radv.demodulate_equalize(inp, eq)
         assert rel_err(g[keep], ref[keep]) < TOL and rel_err(r[keep], ref[keep]) < TOL
+
+
+def test_rader_timeslot_transforms_match_the_dense_forms_and_the_oracle():
+    """The reference's QA shape (python/qa_simple_receiver_cc.py:58-83, qa_simple_modulator_cc.py: 127 timeslots, 16 subcarriers) runs its plain
+    blocks on the Rader kernels (csrc/gfdm_rader.hip): every entry point they serve against the float64 oracle at 1e-5 and against the dense
+    transforms of the generic kernels -- vector ALU (mode 0) and matrix cores (mode 2) -- at 2e-6, for overlap 2 and 4 (filter in registers), 3 and 6
+    (run-time filter loop), real and complex taps, batches that do not fill a wave generation; the paths the Rader kernels do not serve
+    (cancellation rounds, frames + demapper) still answer correctly on such a handle."""
+    import gfdm_amd
+    M, K = 127, 16
+    N = M * K
+    rng = np.random.default_rng(127)
+    for L, alpha, cplx in ((2, 0.5, False), (4, 0.5, False), (3, 0.3, False), (6, 0.2, True)):
+        taps = get_frequency_domain_filter("rrc", alpha, M, K, L)
+        if cplx:
+            taps = taps * np.exp(2j * np.pi * rng.random(M * L)) * (1 + 0.2 * rng.standard_normal(M * L))
+        nt = R.normalize_taps(taps, M)
+        fam = {}
+        for mode, want in ((1, "generic_rader"), (0, "generic_lds"), (2, "generic_lds")):
+            prev = gfdm_amd.set_dft_matrix_cores(mode)
+            try:
+                fam[mode] = (gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps))
+            finally:
+                gfdm_amd.set_dft_matrix_cores(prev)
+            assert fam[mode][0].kernel_name() == want and fam[mode][1].kernel_name() == want
+        for B in (1, 5, 300):
+            d = qpsk(rng, (B, N)) + 0.1 * (rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N)))
+            x = R.modulate(d, nt, M, K, L) + 0.05 * (rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N)))
+            feq = np.fft.fft(np.array([1, .5, .1j, .1 + .05j]), N)[None, :] * np.exp(0.01j * np.arange(B))[:, None]
+            ref = {"mod": R.modulate(d, nt, M, K, L), "mf": R.demodulate(x, nt, M, K, L), "zf": R.demodulate(x, nt, M, K, L, f_eq=feq),
+                   "fd": R.fft_filter_downsample(x, nt, M, K, L), "fdeq": R.fft_filter_downsample(x, nt, M, K, L, feq)}
+            got = {}
+            for mode, (mod, dem) in fam.items():
+                got[mode] = {"mod": mod.modulate(d), "mf": dem.demodulate(x), "zf": dem.demodulate_equalize(x, feq),
+                             "fd": dem.fft_filter_downsample(x), "fdeq": dem.fft_equalize_filter_downsample(x, feq)}
+            for k in ref:
+                check_err("rader_%s_L%d_B%d" % (k, L, B), rel_err(got[1][k], ref[k]), TOL)
+                assert rel_err(got[1][k], got[0][k]) < 2e-6 and rel_err(got[1][k], got[2][k]) < 2e-6
+    # what the Rader kernels do not serve: cancellation rounds, frames in / demapped symbols out -- same handle kind, generic kernels
+    taps = get_frequency_domain_filter("rrc", 0.3, M, K, 2)
+    nt = R.normalize_taps(taps, M)
+    smap = np.arange(1, K - 1)
+    dsym = np.zeros((4, K, M), complex)
+    dsym[:, smap, :] = qpsk(rng, (4, len(smap), M))
+    x = R.modulate(dsym.reshape(4, N), nt, M, K, 2)
+    adv = gfdm_amd.AdvancedReceiver(M, K, 2, taps, smap, 2, R.qpsk_points())
+    assert adv.kernel_name() == "generic_rader"
+    ref, st = R.advanced_receive(x, nt, M, K, 2, smap, R.qpsk_points(), 2, kind="qpsk", return_stages=True)
+    keep = guarded(st, smap, K, M)
+    assert keep.sum() >= 3 and rel_err(adv.demodulate(x)[keep], ref[keep]) < TOL
+    dem = gfdm_amd.Demodulator(M, K, 2, taps)
+    dem.configure_frames(N + 9, 6, smap, True)
+    frames = np.concatenate((x[:, -6:], x, x[:, :3]), axis=1)
+    assert rel_err(dem.demodulate_frames(frames), R.demap_from_resources(R.demodulate(x, nt, M, K, 2), M, K, smap, True)) < TOL
 
 
 def test_ic_with_complex_asymmetric_taps_uses_general_convolution():
