@@ -274,7 +274,11 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True, kernel_seconds
         e1.record()
         torch.cuda.synchronize()
         kern_ms.append(e0.elapsed_time(e1) / steps)
-        kern_single.append(single_launch_ms(lambda i: step_fns[(warmup + i) % nslots][j](), min(steps, 200)))
+        # (at least 200 pairs behind a warm-up run of 50 launches, whatever --steps is: the driver's 20-step line took 20 pairs right behind an idle
+        # gap and read the clock ramp of that moment -- 15.1 us against 9.2-11.6 us by every other reading of the same run, profiles/r05/)
+        for i in range(50):
+            step_fns[i % nslots][j]()
+        kern_single.append(single_launch_ms(lambda i: step_fns[(warmup + i) % nslots][j](), max(200, min(steps, 1000))))
         kern_sus.append(sustained_launch_ms(lambda i: step_fns[i % nslots][j](), kernel_seconds, kern_single[-1])[0] if kernel_seconds > 0 else None)
     return wall, kern_ms, kern_single, kern_sus
 

@@ -111,6 +111,15 @@ def test_roofline_traffic_comes_from_the_committed_pmc_summary():
         assert 1.0 <= tr["bytes"] / (bytes_per_block * 4096) < 1.05
         other = bench.pmc_traffic(kernel, 4096, "0123456789abcdef")
         assert other["bytes"] is None and "build" in other["note"]
+    # ... and so is `roofline.kernel_ms_rocprofv3` (profiles/rNN/kernel_alone.csv + build_id.txt): the rocprofv3 duration of the same build or null + a note
+    for kernel, batch, bytes_per_block in (("k_row_modulate<64, 9, 2, 0>", 4096, 16 * 576), ("k_row_receive<64, 9, 2, 2, 1, 1>", 4096, 24 * 576),
+                                           ("k_row_receive<64, 9, 2, 2, 1, 1>", 65536, 24 * 576), ("k_row_receive<128, 15, 4, 2, 0, 2>", 65536, 16 * 1920)):
+        rp = bench.rocprof_kernel_ms(kernel, batch)
+        assert rp["ms"] is not None and rp["source"].startswith("profiles/r")
+        assert 0.3 < bytes_per_block * batch / (rp["ms"] * 1e-3) / 8e12 < 0.85             # a fraction of the 8 TB/s peak in the range this hardware gives
+        other = bench.rocprof_kernel_ms(kernel, batch, "0123456789abcdef")
+        assert other["ms"] is None and "build" in other["note"]
+    assert bench.rocprof_kernel_ms("k_row_receive<64, 9, 2, 1, 0, 0>", 4097)["ms"] is None
     none = bench.pmc_traffic("k_row_receive<64, 9, 2, 1, 0, 0>", 4097)
     assert none["bytes"] is None and none["note"]
     assert set(bench.CONFIGS) == {"cfg2", "cfg3", "cfg4", "cfg5"} and bench.CONFIGS["cfg4"]["total"] == bench.CONFIGS["cfg5"]["total"] == 65536
