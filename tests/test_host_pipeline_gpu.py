@@ -251,6 +251,8 @@ def test_sharded_host_batches_run_their_devices_concurrently(pipeline):
     whole = g.Demodulator(M, K, L, taps).demodulate(x)
     parts = sb.run_global("demodulate", [x], [N])
     assert [(s, n) for s, n, _ in parts] == [(i * 4096, 4096) for i in range(4)]
+    # the statistics of a host call belong to the thread that made it: run_global keeps every shard's own
+    assert len(sb.last_host_call_stats) == 4 and all(st["chunks"] >= 2 and st["staged_bytes"] == 16 * N * 4096 for st in sb.last_host_call_stats)
     assert np.array_equal(np.concatenate([p for _, _, p in parts]), whole)
     serial, threaded = [], []
     for _ in range(5):
@@ -351,6 +353,15 @@ def test_memory_pinned_or_owned_by_somebody_else(pipeline):
     od = torch.empty_like(xd)
     assert g.lib().gfdm_hip_receiver_demodulate_host(dem._h, ctypes.c_void_p(od.data_ptr()), ctypes.c_void_p(xd.data_ptr()), None, ctypes.c_int64(nb)) == 0
     assert g.host_call_stats()["direct_mask"] == 0b11 and np.array_equal(od.cpu().numpy(), ref)
+    # device memory is never bounced (a CPU copy would dereference a device address): an interior slice of a device allocation is used in place as
+    # well, and a device output that overlaps its input is refused instead of being staged
+    big = torch.zeros(nb + 10, N, dtype=torch.complex64, device="cuda")
+    big[5:5 + nb] = xd
+    od.zero_()
+    assert g.lib().gfdm_hip_receiver_demodulate_host(dem._h, ctypes.c_void_p(od.data_ptr()), ctypes.c_void_p(big[5].data_ptr()), None, ctypes.c_int64(nb)) == 0
+    assert g.host_call_stats()["direct_mask"] == 0b11 and np.array_equal(od.cpu().numpy(), ref)
+    assert g.lib().gfdm_hip_receiver_demodulate_host(dem._h, ctypes.c_void_p(big[6].data_ptr()), ctypes.c_void_p(big[5].data_ptr()), None, ctypes.c_int64(nb)) == g.capi.EINVAL
+    assert b"overlaps" in g.lib().gfdm_hip_last_error()
 
 
 @pytest.mark.parametrize("threads", [0, 3])

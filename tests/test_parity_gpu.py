@@ -578,6 +578,24 @@ def test_ic_rounds_on_the_matrix_cores_match_the_vector_alu(M, K, L, alpha):
         assert rel_err(mx.demodulate_frames(frames)[keep], want[keep]) < TOL
 
 
+def test_decision_rule_a_handle_runs_is_reported():
+    """gfdm_hip_advanced_receiver_decision: the sign tests (and with them the matrix-core cancellation rounds) only for GNU Radio's unit QPSK / BPSK
+    points -- every component within four float32 ulps --; scaled, rotated or perturbed points are decided by the nearest-point rule over the points
+    as given, also when 'qpsk' / 'bpsk' was asked for, and the handle says so."""
+    import gfdm_amd
+    M, K, L = 9, 64, 2
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    q = R.qpsk_points()
+    mk = lambda pts, dec: gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, pts, decision=dec).decision_rule()
+    assert mk(q, "auto") == "qpsk" and mk(q, "qpsk") == "qpsk" and mk(q, "nearest") == "nearest"
+    assert mk(q.astype(np.complex64) * np.complex64(1 + 1.2e-7), "auto") == "qpsk"           # one or two ulps off: still the unit constellation
+    assert mk(q * (1 + 1e-6), "auto") == "nearest" and mk(q * (1 + 1e-6), "qpsk") == "nearest"
+    assert mk(2 * q, "qpsk") == "nearest" and mk(q * np.exp(0.3j), "qpsk") == "nearest"
+    assert mk(np.array([-1, 1]), "auto") == "bpsk" and mk(np.array([-2, 2]), "bpsk") == "nearest"
+    with pytest.raises(ValueError):
+        mk(q[:3], "qpsk")                                                                     # rule and number of points do not match
+
+
 def test_phase_compensation_removes_a_common_phase():
     """The known answer of tests/test_oracle.py::test_phase_compensation_removes_a_common_phase on the HIP path
     (lib/advanced_receiver_kernel_cc.cc:59-71,78-91): with phase compensation the receiver output does not depend on a common phase of
