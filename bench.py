@@ -404,6 +404,37 @@ def pin_rank(local_rank, local_world):
     return mine
 
 
+def parse_cpulist(text):
+    """'0-31,128-159' -> [0, ..., 31, 128, ..., 159]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def numa_slice(pci_bus_ids, local_rank, allowed, read=None):
+    """This rank's share of the CPUs next to ITS GPU: every local rank's GPU (PCI bus id, as torch reports it) is looked up in sysfs
+    (/sys/bus/pci/devices/<id>/local_cpulist), the ranks whose GPUs hang off the same CPUs split those (intersected with the CPUs this
+    process may use) evenly in rank order.  None when anything is missing -- the caller keeps the plain slice by LOCAL_RANK.  On a two-socket
+    node the plain slices put ranks 2, 3 (and their launch loops' doorbell writes) on the other socket than GPUs 2, 3."""
+    if read is None:
+        read = lambda bdf: open("/sys/bus/pci/devices/%s/local_cpulist" % bdf.lower()).read()
+    try:
+        lists = [tuple(c for c in parse_cpulist(read(b)) if c in allowed) for b in pci_bus_ids]
+    except (OSError, ValueError):
+        return None
+    mine = lists[local_rank]
+    group = [r for r, l in enumerate(lists) if l == mine]
+    per = len(mine) // len(group)
+    if per < 1:
+        return None
+    i = group.index(local_rank)
+    return list(mine[i * per:(i + 1) * per])
+
+
 def pin_launch_thread(cpu_slice):
     """the calling (launch) thread onto the first CPU of its rank's slice; threads that exist already keep the whole slice"""
     if not cpu_slice:
@@ -633,6 +664,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    try:
+        allowed_cpus_at_start = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed_cpus_at_start = []
     cpu_slice = None if (a.no_pin or world == 1) else pin_rank(local % max(1, local_world), local_world)     # before torch is imported
     if a.selftest_launch:
         return selftest_launch(a, cfg, rank, world, cpu_slice)
@@ -646,6 +681,18 @@ def main():
         local = local % torch.cuda.device_count()                    # test mode: the ranks may share a GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if cpu_slice is not None and a.dist_backend == "nccl":          # one GPU per rank: move the slice next to this rank's GPU when sysfs says where that is
+        try:
+            ids = []
+            for j in range(local_world):
+                pr = torch.cuda.get_device_properties(j)
+                ids.append("%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id))
+            near = numa_slice(ids, local, set(allowed_cpus_at_start))
+            if near:
+                os.sched_setaffinity(0, near)
+                cpu_slice = near
+        except Exception:                                           # (placement is an optimisation: never a reason to fail the run)
+            pass
     # torch.distributed: always for N > 1; for one rank when asked (--force-dist) or when a torchrun environment is present (WORLD_SIZE=1),
     # so that the RCCL group, the barriers and the two all-reduces of sharding.reduce_stats also run on a one-GPU box
     use_dist = world > 1 or a.force_dist or "WORLD_SIZE" in os.environ

@@ -82,6 +82,28 @@ def test_eight_ranks_shard_plan_statistics_and_placement():
             assert len({p["cpu_first"] for p in place}) == 8
 
 
+def test_numa_slices_follow_the_gpus():
+    """bench.py moves a rank's CPU slice next to its GPU when sysfs tells where that is: on a two-socket node (GPUs 0-3 on the CPUs of socket 0,
+    4-7 on socket 1, hyperthread siblings numbered behind) every rank gets an eighth of ITS socket's CPUs, disjoint from the others; an unreadable
+    entry leaves the plain slices."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module_numa", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    ids = ["0000:%02x:00.0" % (0x10 + j) for j in range(8)]
+    read = lambda bdf: "0-63,128-191" if int(bdf[5:7], 16) - 0x10 < 4 else "64-127,192-255"
+    allowed = set(range(256))
+    slices = [bench.numa_slice(ids, r, allowed, read) for r in range(8)]
+    assert all(len(sl) == 32 for sl in slices) and len(set(c for sl in slices for c in sl)) == 256
+    assert all(c < 64 or 128 <= c < 192 for r in range(4) for c in slices[r]) and all(64 <= c < 128 or c >= 192 for r in range(4, 8) for c in slices[r])
+    assert bench.numa_slice(ids, 3, set(range(0, 256, 2)), read) == [c for c in bench.parse_cpulist("0-63,128-191") if c % 2 == 0][48:64]     # inside a restricted mask
+
+    def missing(bdf):
+        raise OSError("no such device")
+    assert bench.numa_slice(ids, 0, allowed, missing) is None and bench.numa_slice(ids, 0, set(), read) is None
+
+
 def test_bench_runs_under_an_external_torchrun_environment():
     """the driver's own launch: torchrun sets WORLD_SIZE, bench.py must then NOT start ranks of its own"""
     env = dict(os.environ, OMP_NUM_THREADS="1")
