@@ -491,6 +491,12 @@ def test_rader_timeslot_transforms_match_the_dense_forms_and_the_oracle():
             for k in ref:
                 check_err("rader_%s_L%d_B%d" % (k, L, B), rel_err(got[1][k], ref[k]), TOL)
                 assert rel_err(got[1][k], got[0][k]) < 2e-6 and rel_err(got[1][k], got[2][k]) < 2e-6
+    # overlap 1 (modulator only: the receiver needs overlap >= 2): half of the bins of a tap part are used, lib/modulator_kernel_cc.cc:101
+    taps1 = get_frequency_domain_filter("rrc", 0.5, M, K, 2)[:M] * np.exp(0.4j * np.arange(M))
+    d = qpsk(rng, (7, N))
+    mod1 = gfdm_amd.Modulator(M, K, 1, taps1)
+    assert mod1.kernel_name() == "generic_rader"
+    check_err("rader_mod_L1", rel_err(mod1.modulate(d), R.modulate(d, R.normalize_taps(taps1, M), M, K, 1)), TOL)
     # what the Rader kernels do not serve: cancellation rounds, frames in / demapped symbols out -- same handle kind, generic kernels
     taps = get_frequency_domain_filter("rrc", 0.3, M, K, 2)
     nt = R.normalize_taps(taps, M)
