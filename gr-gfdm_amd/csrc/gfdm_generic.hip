@@ -1120,7 +1120,7 @@ hipError_t launch_generic_receive(const DevicePlan& p, const IcParams& ic, const
                                   int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    if (rader_applies_receive(p, ic, est, mode)) return launch_rader_receive(p, mode, out, in, f_eq, nblocks, s);
+    if (rader_applies_receive(p, ic, est, mode)) return launch_rader_receive(p, ic, mode, out, in, f_eq, nblocks, s);
     const int eq_source = est ? EQ_PREAMBLE : f_eq ? EQ_VECTOR : EQ_NONE;
     if (est && p.M < 2) return hipErrorInvalidConfiguration;               // the tiles double as the estimator's 2K scratch
     const size_t extra = est ? (size_t)(2 * p.K + 2) * sizeof(cf) : 0;     // K-bin estimate + smoothed estimate

@@ -103,7 +103,7 @@ bool rader_supports(int M, int K);
 bool rader_applies_modulate(const DevicePlan& p, const TxParams& tx);
 bool rader_applies_receive(const DevicePlan& p, const IcParams& ic, const EstPlan* est, int mode);
 hipError_t launch_rader_modulate(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s);
-hipError_t launch_rader_receive(const DevicePlan& p, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks, hipStream_t s);
+hipError_t launch_rader_receive(const DevicePlan& p, const IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks, hipStream_t s);
 
 // ---- row-lane family (gfdm_rowlane_impl.h, dispatch in gfdm_rowlane.hip): one lane per subcarrier row, in-place radix-4 passes ----
 bool rowlane_supports(int M, int K, int L);

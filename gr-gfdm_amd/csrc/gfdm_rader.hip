@@ -18,8 +18,9 @@
 // equaliser and the filter: load -> Rader rows -> columns -> Rader rows -> store, 8 barriers per block, two tiles of LDS (33.4 KB: four blocks per CU).
 // Vector-ALU bound (SQ counters: ~1500 vector instructions per wave, the vector pipe ~90 % busy at four waves per SIMD).
 //
-// Serves plain blocks: modulate, fft_[equalize_]filter_downsample, generic_work[_equalize].  Everything else of this shape -- cancellation rounds,
-// frames / demapper, the self-estimating receivers, the fused transmitter -- stays on the generic kernels (launch_generic_* falls through).
+// Serves plain blocks: modulate, fft_[equalize_]filter_downsample, generic_work[_equalize] and the advanced receiver's cancellation rounds (incl. phase
+// compensation).  Everything else of this shape -- frames / demapper, the self-estimating receivers, the fused transmitter -- stays on the generic
+// kernels (launch_generic_* falls through).
 #include "gfdm_plan.h"
 #include "gfdm_dft.h"
 #include "gfdm_tx.h"
@@ -126,14 +127,16 @@ __device__ __forceinline__ cf cdiv(cf a, cf b)                   // (v_rcp_f32: 
 // read of the modulator's store take the minimum of two LDS cycles per wavefront).  W: work tile of a row transform as A planes [j1][row * B + p2]
 // at plane stride PL -- stage 1 writes and stage 3 reads it with consecutive lanes on consecutive elements, stage 2's accesses (lane = (row, j1)) spread
 // over the banks for an odd PL (simulated: 2.3 cycles per access against the minimum of 2).  X0: output 0 of every row.  BS: the kernel spectrum.
-template <int K, int P, int A, int B>
+// S2 (receivers with cancellation rounds only): the filtered spectra S, which every round cancels against.
+template <int K, int P, int A, int B, bool IC = false>
 struct RaderLds {
     static constexpr int TS = 132, PL = K * B + 1;
-    static_assert(TS >= P && PL >= K * B && (PL & 1) == 1, "tile strides");
+    static_assert(TS >= P && PL >= K * B && (PL & 1) == 1 && A * PL * 2 >= RT, "tile strides");
     cf T[K * TS];
     cf W[A * PL];
     cf BS[A * B];
     cf X0[K];
+    cf S2[IC ? K * TS : 1];
 };
 
 // Forward P-point transforms of ROWS rows at once (all RT threads call; the caller has made the sources visible and synchronises before it reads
@@ -195,15 +198,40 @@ __device__ __forceinline__ void rader_prologue(Lds& lds, const cf* __restrict__ 
     if (t < A * B) lds.BS[t] = bs[t];
 }
 
+// hard decision of the cancellation rounds (gr::digital::constellation::decision_maker at lib/advanced_receiver_kernel_cc.cc:119): QPSK / BPSK sign tests
+// (zero -> the negative point) or the nearest of the points, first minimum
+__device__ __forceinline__ cf rader_decide(cf x, const IcParams& ic)
+{
+    int idx;
+    if (ic.decision == 1) {
+        idx = 2 * (x.y > 0.f) + (x.x > 0.f);
+    } else if (ic.decision == 2) {
+        idx = (x.x > 0.f);
+    } else {
+        idx = 0;
+        float best = INFINITY;
+        for (int i = 0; i < ic.npoints; ++i) {
+            const cf pt = ic.points[i];
+            const float dr = x.x - pt.x, di = x.y - pt.y, d = dr * dr + di * di;
+            if (d < best) { best = d; idx = i; }
+        }
+    }
+    return ic.points[idx];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-// receiver: fft_[equalize_]filter_downsample (RX_FD) / generic_work[_equalize] (RX_DEMOD)
+// receiver: fft_[equalize_]filter_downsample (RX_FD) / generic_work[_equalize] (RX_DEMOD) / advanced receiver (IC: RX_DEMOD + cancellation rounds)
 //   lib/receiver_kernel_cc.cc:165-192, 211-225, 301-334
 // LT: the overlap when it is 2 or 4 (the filter then runs on the column in registers), 0 = any overlap (run-time loop through the tile)
-template <int K, int P, int A, int B, int LT>
-__global__ __launch_bounds__(RT, 4) void k_rader_receive(DevicePlan p, int mode, cf* __restrict__ out, const cf* __restrict__ in, const cf* __restrict__ f_eq)
+// IC: cancellation rounds of advanced_receiver_kernel_cc::perform_ic_iterations (lib/advanced_receiver_kernel_cc.cc:56-76) in the reference's own
+// frequency-domain form, S' = S - ic (.) DFT_M(dec_{k-1} + dec_{k+1}), d = IDFT_M(S') / M: two more row transforms per round, S kept in a third tile
+// (three blocks per CU instead of four, which is why the plain receivers are an instantiation of their own).
+template <int K, int P, int A, int B, int LT, bool IC>
+__global__ __launch_bounds__(RT, IC ? 3 : 4) void k_rader_receive(DevicePlan p, IcParams ic, int mode, cf* __restrict__ out, const cf* __restrict__ in,
+                                                                 const cf* __restrict__ f_eq)
 {
     constexpr int N = K * P;
-    typedef RaderLds<K, P, A, B> Lds;
+    typedef RaderLds<K, P, A, B, IC> Lds;
     constexpr int TS = Lds::TS;
     __shared__ __attribute__((aligned(16))) Lds lds;
     cf* T = lds.T;
@@ -256,6 +284,7 @@ __global__ __launch_bounds__(RT, 4) void k_rader_receive(DevicePlan p, int mode,
         }
         if (mode == RX_FD) static_for<0, K>([&](auto i) { constexpr int k = decltype(i)::value; dft::st_stream(o, k * P + t, s[k]); });
         else static_for<0, K>([&](auto i) { constexpr int k = decltype(i)::value; T[k * TS + t] = s[k]; });
+        if constexpr (IC) static_for<0, K>([&](auto i) { constexpr int k = decltype(i)::value; lds.S2[k * TS + t] = s[k]; });
     }
     if (mode == RX_FD) return;
     __syncthreads();
@@ -264,6 +293,55 @@ __global__ __launch_bounds__(RT, 4) void k_rader_receive(DevicePlan p, int mode,
     rader_rows<K, P, A, B>(lds, min, mneg, [&](int k, int pos) { return T[k * TS + pos]; },        // (mneg: output m is written at P - m; m = 0 stays)
                            [&](int k, int m, cf v) { T[k * TS + m] = make_float2(v.x * invM, v.y * invM); }, [] {});
     __syncthreads();
+    if constexpr (IC) {
+        cf* S2 = lds.S2;
+        for (int j = 0; j < ic.ic_iter; ++j) {
+            if (ic.do_phase_compensation > 0 && j == 0) {
+                // calculate_phase_offset (adv:78-91): phi = mean over the MAP's symbols of arg(decision) - arg(symbol), no unwrapping; S turns by it and keeps
+                // the turn (adv:63-70).  The decisions below are taken on the symbols as they are (decision before rotation).
+                float acc = 0.f;
+                for (int idx = t; idx < ic.n_active * P; idx += RT) {
+                    const int a = idx / P, m = idx - a * P;
+                    const cf v = T[ic.smap[a] * TS + m];
+                    const cf d = rader_decide(v, ic);
+                    acc += atan2f(d.y, d.x) - atan2f(v.y, v.x);
+                }
+                float* red = reinterpret_cast<float*>(lds.W);                      // (the work tile is free between transforms)
+                red[t] = acc;
+                __syncthreads();
+                for (int sft = RT / 2; sft > 0; sft >>= 1) {
+                    if (t < sft) red[t] += red[t + sft];
+                    __syncthreads();
+                }
+                const float phi = red[0] / (float)(ic.n_active * P);
+                float sn, cs;
+                sincosf(phi, &sn, &cs);
+                const cf rot = make_float2(cs, sn);
+                __syncthreads();                                                   // (everybody has read red[0] before the next transform writes the tile)
+                for (int i = t; i < N; i += RT) { const int k = i / P, m = i - k * P; S2[k * TS + m] = cmul(S2[k * TS + m], rot); }
+            }
+            // map_symbols_to_constellation_points (adv:109-123): block zeroed, the map's subcarriers decided -- in place
+            for (int i = t; i < N; i += RT) {
+                const int k = i / P, m = i - k * P;
+                T[k * TS + m] = ic.active[k] ? rader_decide(T[k * TS + m], ic) : make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+            // S'[k][m] = S[k][m] - ic[m] DFT_M(dec_{k-1} + dec_{k+1})[m]     (receiver_kernel_cc.cc:274-299; neighbours wrap mod K)
+            rader_rows<K, P, A, B>(lds, min, mout,
+                                   [&](int k, int pos) {
+                                       const cf a = T[((k + K - 1) & (K - 1)) * TS + pos], b = T[((k + 1) & (K - 1)) * TS + pos];
+                                       return make_float2(a.x + b.x, a.y + b.y);
+                                   },
+                                   [&](int k, int m, cf v) {
+                                       const cf c = cmul(p.ictaps[m], v), sv = S2[k * TS + m];
+                                       T[k * TS + m] = make_float2(sv.x - c.x, sv.y - c.y);
+                                   }, [] {});
+            __syncthreads();
+            rader_rows<K, P, A, B>(lds, min, mneg, [&](int k, int pos) { return T[k * TS + pos]; },
+                                   [&](int k, int m, cf v) { T[k * TS + m] = make_float2(v.x * invM, v.y * invM); }, [] {});
+            __syncthreads();
+        }
+    }
     for (int i = t; i < N; i += RT) dft::st_stream(o, i, T[(i / P) * TS + i % P]);
 }
 
@@ -372,7 +450,7 @@ bool rader_applies_receive(const DevicePlan& p, const IcParams& ic, const EstPla
 {
     if (p.raderB == nullptr || !rader_supports(p.M, p.K) || est != nullptr) return false;
     if (ic.io.in_stride != 0 || ic.io.in_offset != 0 || ic.io.demap) return false;
-    return mode == RX_FD || mode == RX_DEMOD || (mode == RX_IC && ic.ic_iter <= 0);
+    return mode == RX_FD || mode == RX_DEMOD || mode == RX_IC;
 }
 
 hipError_t launch_rader_modulate(const DevicePlan& p, cf* out, const cf* in, int64_t nblocks, hipStream_t s)
@@ -383,11 +461,16 @@ hipError_t launch_rader_modulate(const DevicePlan& p, cf* out, const cf* in, int
     return hipGetLastError();
 }
 
-hipError_t launch_rader_receive(const DevicePlan& p, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks, hipStream_t s)
+hipError_t launch_rader_receive(const DevicePlan& p, const IcParams& ic, int mode, cf* out, const cf* in, const cf* f_eq, int64_t nblocks, hipStream_t s)
 {
     if (nblocks <= 0) return hipSuccess;
-    auto kern = p.L == 2 ? k_rader_receive<16, 127, RA, RB, 2> : p.L == 4 ? k_rader_receive<16, 127, RA, RB, 4> : k_rader_receive<16, 127, RA, RB, 0>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(RT), 0, s, p, mode == RX_FD ? RX_FD : RX_DEMOD, out, in, f_eq);
+    if (mode == RX_IC && ic.ic_iter > 0) {
+        auto kern = p.L == 2 ? k_rader_receive<16, 127, RA, RB, 2, true> : p.L == 4 ? k_rader_receive<16, 127, RA, RB, 4, true> : k_rader_receive<16, 127, RA, RB, 0, true>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(RT), 0, s, p, ic, (int)RX_DEMOD, out, in, f_eq);
+        return hipGetLastError();
+    }
+    auto kern = p.L == 2 ? k_rader_receive<16, 127, RA, RB, 2, false> : p.L == 4 ? k_rader_receive<16, 127, RA, RB, 4, false> : k_rader_receive<16, 127, RA, RB, 0, false>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(RT), 0, s, p, ic, mode == RX_FD ? (int)RX_FD : (int)RX_DEMOD, out, in, f_eq);
     return hipGetLastError();
 }
 

@@ -110,10 +110,10 @@ int gfdm_hip_set_ic_matrix_cores(int mode);
  * (returns the previous mode): 0 = vector ALU only, 1 (default) = matrix cores where they are the faster form (the 16 x 16 x 4 operand tiles
  * well filled, at least four of them per block, and the operand scratch does not cost the CU its second workgroup), 2 = wherever the form fits.
  * In mode 1 the reference's own QA shape -- 127 timeslots, 16 subcarriers (python/qa_simple_receiver_cc.py:58-83) -- does not use dense
- * transforms at all for plain blocks (modulate, fft_[equalize_]filter_downsample, generic_work[_equalize]): its 127-point transforms are
- * Rader transforms, cyclic convolutions of length 126 = 14 x 9 through prime-factor FFTs (csrc/gfdm_rader.hip; kernel_name "generic_rader");
- * cancellation rounds, frames / demapper and the self-estimating receivers of that shape stay on the generic kernels.  Modes 0 and 2 keep
- * the dense forms for that shape too (A/B, tests). */
+ * transforms at all for plain blocks (modulate, fft_[equalize_]filter_downsample, generic_work[_equalize], the advanced receiver's cancellation
+ * rounds): its 127-point transforms are Rader transforms, cyclic convolutions of length 126 = 9 x 14 through prime-factor FFTs
+ * (csrc/gfdm_rader.hip; kernel_name "generic_rader"); frames / demapper and the self-estimating receivers of that shape stay on the generic
+ * kernels.  Modes 0 and 2 keep the dense forms for that shape too (A/B, tests). */
 int gfdm_hip_set_dft_matrix_cores(int mode);
 /* TEST HOOK: compile (or find in the disk cache) part 0..4 (receive, receive + IC, preamble-equalised receive, modulate, estimator) of
  * the row-lane kernels for a shape through hiprtc WITHOUT loading it --

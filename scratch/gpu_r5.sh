@@ -48,8 +48,8 @@ alone)
   done
   for b in 4096 65536; do   # the reference's QA shape (127 timeslots, 16 subcarriers): Rader kernels, and the dense matrix-core form beside them (GFDM_DFT_MX=2)
     reps=100; slots=12; [ $b = 65536 ] && { reps=20; slots=2; }
-    for p in modulate demod_mf demod_zf; do trace $O/kernel_alone.csv 16_127_2_${p}_$b $((reps / 2)) $p $b $reps $slots 16 127 2; done
-    for p in modulate demod_mf demod_zf; do GFDM_DFT_MX=2 trace $O/kernel_alone.csv 16_127_2_dense_${p}_$b $((reps / 2)) $p $b $reps $slots 16 127 2; done
+    for p in modulate demod_mf demod_zf demod_mf_ic2 demod_zf_ic2; do trace $O/kernel_alone.csv 16_127_2_${p}_$b $((reps / 2)) $p $b $reps $slots 16 127 2; done
+    for p in modulate demod_mf demod_zf demod_mf_ic2 demod_zf_ic2; do GFDM_DFT_MX=2 trace $O/kernel_alone.csv 16_127_2_dense_${p}_$b $((reps / 2)) $p $b $reps $slots 16 127 2; done
   done
   cat $O/kernel_alone.csv | cut -d, -f1-2,8- ;;
 pmc)
@@ -59,7 +59,7 @@ pmc)
               "demod_mf_ic2 8192 128 15 4" "demod_mf_ic2 65536 128 15 4" "demod_zf 8192 256 31 2" "demod_zf 65536 256 31 2"}; do
     set -- $spec; run=$1_$3_$4_$5_$2; reps=40; [ $2 -ge 65536 ] && reps=12; [ $2 -ge 65536 ] && [ $3 -ge 256 ] && reps=6
     for c in FETCH_SIZE WRITE_SIZE; do
-      timeout 300 rocprofv3 --pmc $c --output-format csv -d $O/pmc/$run/$c -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
+      timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc/$run/$c -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
     done
   done
   python3 $R/scratch/pmc_summary.py $O/pmc $id > $O/pmc_hbm_traffic_summary.csv; rm -rf $O/pmc

@@ -459,8 +459,8 @@ def test_rader_timeslot_transforms_match_the_dense_forms_and_the_oracle():
     """The reference's QA shape (python/qa_simple_receiver_cc.py:58-83, qa_simple_modulator_cc.py: 127 timeslots, 16 subcarriers) runs its plain
     blocks on the Rader kernels (csrc/gfdm_rader.hip): every entry point they serve against the float64 oracle at 1e-5 and against the dense
     transforms of the generic kernels -- vector ALU (mode 0) and matrix cores (mode 2) -- at 2e-6, for overlap 2 and 4 (filter in registers), 3 and 6
-    (run-time filter loop), real and complex taps, batches that do not fill a wave generation; the paths the Rader kernels do not serve
-    (cancellation rounds, frames + demapper) still answer correctly on such a handle."""
+    (run-time filter loop), real and complex taps, batches that do not fill a wave generation; the advanced receiver's cancellation rounds on the same
+    kernels; the paths the Rader kernels do not serve (frames + demapper) still answer correctly on such a handle."""
     import gfdm_amd
     M, K = 127, 16
     N = M * K
@@ -497,22 +497,40 @@ def test_rader_timeslot_transforms_match_the_dense_forms_and_the_oracle():
     mod1 = gfdm_amd.Modulator(M, K, 1, taps1)
     assert mod1.kernel_name() == "generic_rader"
     check_err("rader_mod_L1", rel_err(mod1.modulate(d), R.modulate(d, R.normalize_taps(taps1, M), M, K, 1)), TOL)
-    # what the Rader kernels do not serve: cancellation rounds, frames in / demapped symbols out -- same handle kind, generic kernels
+    # the advanced receiver's cancellation rounds (two more row transforms per round, S in a third tile): MF and ZF input, a partial subcarrier map, 1-3 rounds,
+    # both decision rules, with and without phase compensation -- against the oracle and against the dense form of the generic kernels
     taps = get_frequency_domain_filter("rrc", 0.3, M, K, 2)
     nt = R.normalize_taps(taps, M)
     smap = np.arange(1, K - 1)
-    dsym = np.zeros((4, K, M), complex)
-    dsym[:, smap, :] = qpsk(rng, (4, len(smap), M))
-    x = R.modulate(dsym.reshape(4, N), nt, M, K, 2)
-    adv = gfdm_amd.AdvancedReceiver(M, K, 2, taps, smap, 2, R.qpsk_points())
-    assert adv.kernel_name() == "generic_rader"
-    ref, st = R.advanced_receive(x, nt, M, K, 2, smap, R.qpsk_points(), 2, kind="qpsk", return_stages=True)
-    keep = guarded(st, smap, K, M)
-    assert keep.sum() >= 3 and rel_err(adv.demodulate(x)[keep], ref[keep]) < TOL
+    B = 5
+    dsym = np.zeros((B, K, M), complex)
+    dsym[:, smap, :] = qpsk(rng, (B, len(smap), M))
+    x = R.modulate(dsym.reshape(B, N), nt, M, K, 2) * np.exp(0.04j)
+    feq = np.fft.fft(np.array([1, .5, .1j, .1 + .05j]), N)[None, :] * np.exp(0.01j * np.arange(B))[:, None]
+    xe = np.fft.ifft(np.fft.fft(x, axis=-1) * feq, axis=-1)
+    for rounds, dec, pc in ((1, "auto", 0), (2, "auto", 0), (3, "nearest", 0), (2, "auto", 1), (2, "nearest", 1)):
+        adv = gfdm_amd.AdvancedReceiver(M, K, 2, taps, smap, rounds, R.qpsk_points(), do_phase_compensation=pc, decision=dec)
+        prev = gfdm_amd.set_dft_matrix_cores(2)
+        try:
+            dense = gfdm_amd.AdvancedReceiver(M, K, 2, taps, smap, rounds, R.qpsk_points(), do_phase_compensation=pc, decision=dec)
+        finally:
+            gfdm_amd.set_dft_matrix_cores(prev)
+        assert (adv.kernel_name(), dense.kernel_name()) == ("generic_rader", "generic_lds")
+        for inp, eq in ((x, None), (xe, feq)):
+            ref, st = R.advanced_receive(inp, nt, M, K, 2, smap, R.qpsk_points(), rounds, f_eq=eq, do_phase_compensation=pc,
+                                         kind="qpsk" if dec == "auto" else "nearest", return_stages=True)
+            keep = guarded(st, smap, K, M)
+            assert keep.sum() >= B - 1
+            got = adv.demodulate(inp) if eq is None else adv.demodulate_equalize(inp, eq)
+            den = dense.demodulate(inp) if eq is None else dense.demodulate_equalize(inp, eq)
+            check_err("rader_ic%d_%s_pc%d" % (rounds, dec, pc), rel_err(got[keep], ref[keep]), TOL)
+            assert rel_err(got[keep], den[keep]) < 5e-6
+    # what the Rader kernels do not serve: frames in / demapped symbols out -- same handle kind, generic kernels
     dem = gfdm_amd.Demodulator(M, K, 2, taps)
     dem.configure_frames(N + 9, 6, smap, True)
-    frames = np.concatenate((x[:, -6:], x, x[:, :3]), axis=1)
-    assert rel_err(dem.demodulate_frames(frames), R.demap_from_resources(R.demodulate(x, nt, M, K, 2), M, K, smap, True)) < TOL
+    xx = x[:4]
+    frames = np.concatenate((xx[:, -6:], xx, xx[:, :3]), axis=1)
+    assert rel_err(dem.demodulate_frames(frames), R.demap_from_resources(R.demodulate(xx, nt, M, K, 2), M, K, smap, True)) < TOL
 
 
 def test_ic_with_complex_asymmetric_taps_uses_general_convolution():
