@@ -56,7 +56,8 @@ pmc)
   rm -rf $O/pmc; mkdir -p $O/pmc
   id=$(python3 -c "import sys; sys.path.insert(0, '$R/gr-gfdm_amd/python'); import gfdm_amd; print(gfdm_amd.build_id())")
   for spec in "modulate 4096 64 9 2" "demod_mf 4096 64 9 2" "demod_zf 4096 64 9 2" "demod_mf_ic2 4096 64 9 2" "demod_zf_ic2 4096 64 9 2" "demod_zf_ic2 65536 64 9 2" \
-              "demod_mf_ic2 8192 128 15 4" "demod_mf_ic2 65536 128 15 4" "demod_zf 8192 256 31 2" "demod_zf 65536 256 31 2"}; do
+              "demod_mf_ic2 8192 128 15 4" "demod_mf_ic2 65536 128 15 4" "demod_zf 8192 256 31 2" "demod_zf 65536 256 31 2" \
+              "demod_mf 4096 16 127 2" "modulate 4096 16 127 2" "demod_zf 4096 16 127 2" "demod_zf_ic2 4096 16 127 2"; do
     set -- $spec; run=$1_$3_$4_$5_$2; reps=40; [ $2 -ge 65536 ] && reps=12; [ $2 -ge 65536 ] && [ $3 -ge 256 ] && reps=6
     for c in FETCH_SIZE WRITE_SIZE; do
       timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/pmc/$run/$c -o pmc -- python3 $R/scratch/run_kernel.py $1 $2 $reps 2 $3 $4 $5 > /dev/null 2>&1
