@@ -36,6 +36,7 @@ int fail(int code, const std::string& msg)
 int fail_hip(hipError_t e, const char* what)
 {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();          // reported here: do not leave it behind as the thread's sticky error
     return GFDM_HIP_EHIP;
 }
 
@@ -116,6 +117,10 @@ struct DeviceGuard {
     bool ok = false;
     explicit DeviceGuard(int dev)
     {
+        // hipGetLastError() is sticky: it keeps the error of ANY earlier failed runtime call of this thread (ours or the application's) until somebody reads
+        // it, and the launchers check their launches with it -- a call must not fail on somebody else's stale error (found by tests/sanitize: an allocation
+        // failure in one constructor failed the next handle's first launch).  Every entry point that launches builds a DeviceGuard first.
+        (void)hipGetLastError();
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         ok = (hipSetDevice(dev) == hipSuccess);
     }

@@ -83,8 +83,7 @@ private:
     unsigned ticket_next_ = 0;
     hipStream_t s_b_ = nullptr;                 // second kernel stream: chunk c + 1 reads across the link while chunk c writes
     hipStream_t s_in_ = nullptr, s_out_ = nullptr;
-    hipEvent_t ev_in_[HOST_MAX_DEPTH] = {}, ev_k_[HOST_MAX_DEPTH] = {};
-    bool have_events_ = false;
+    hipEvent_t ev_in_[HOST_MAX_DEPTH] = {}, ev_k_[HOST_MAX_DEPTH] = {};      // nullptr = not created (yet)
 
     int ensure_set(int i, size_t host_bytes, size_t dev_bytes);
     int ensure_ticket();

@@ -56,10 +56,10 @@ constexpr int kTicketStride = 16;               // one 64-byte line per completi
 
 size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
-__global__ void k_host_ticket(volatile unsigned* ticket, unsigned value)
+// (a system-scope release store: everything the kernels in front of it on the stream wrote is visible to the host thread whose acquire load reads `value`)
+__global__ void k_host_ticket(unsigned* ticket, unsigned value)
 {
-    __threadfence_system();
-    *ticket = value;
+    __hip_atomic_store(ticket, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- bounce copies -------------------------------------------------------------------------------------------------------------------
@@ -289,9 +289,11 @@ void HostPipe::release()
     }
     if (ticket_) (void)hipHostFree(ticket_);
     ticket_ = ticket_dev_ = nullptr;
-    if (have_events_)
-        for (int i = 0; i < HOST_MAX_DEPTH; ++i) { (void)hipEventDestroy(ev_in_[i]); (void)hipEventDestroy(ev_k_[i]); }
-    have_events_ = false;
+    for (int i = 0; i < HOST_MAX_DEPTH; ++i) {
+        if (ev_in_[i]) (void)hipEventDestroy(ev_in_[i]);
+        if (ev_k_[i]) (void)hipEventDestroy(ev_k_[i]);
+        ev_in_[i] = ev_k_[i] = nullptr;
+    }
     if (s_in_) (void)hipStreamDestroy(s_in_);
     if (s_out_) (void)hipStreamDestroy(s_out_);
     if (s_b_) (void)hipStreamDestroy(s_b_);
@@ -345,13 +347,13 @@ int HostPipe::ensure_ticket()
 
 int HostPipe::ensure_copy_engines()
 {
-    if (!s_in_ && hipStreamCreateWithFlags(&s_in_, hipStreamNonBlocking) != hipSuccess) return api_fail(GFDM_HIP_EHIP, "hipStreamCreate");
-    if (!s_out_ && hipStreamCreateWithFlags(&s_out_, hipStreamNonBlocking) != hipSuccess) return api_fail(GFDM_HIP_EHIP, "hipStreamCreate");
-    if (!have_events_) {
-        for (int i = 0; i < HOST_MAX_DEPTH; ++i)
-            if (hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_k_[i], hipEventDisableTiming) != hipSuccess)
-                return api_fail(GFDM_HIP_EHIP, "hipEventCreate");
-        have_events_ = true;
+    if (!s_in_ && hipStreamCreateWithFlags(&s_in_, hipStreamNonBlocking) != hipSuccess) { s_in_ = nullptr; (void)hipGetLastError(); return api_fail(GFDM_HIP_EHIP, "hipStreamCreate"); }
+    if (!s_out_ && hipStreamCreateWithFlags(&s_out_, hipStreamNonBlocking) != hipSuccess) { s_out_ = nullptr; (void)hipGetLastError(); return api_fail(GFDM_HIP_EHIP, "hipStreamCreate"); }
+    // (each event on its own: a creation that fails half way leaves the ones made so far to release() and to the next attempt -- the all-or-nothing flag this
+    // replaces leaked them, found by the injected failures of tests/sanitize)
+    for (int i = 0; i < HOST_MAX_DEPTH; ++i) {
+        if (!ev_in_[i] && hipEventCreateWithFlags(&ev_in_[i], hipEventDisableTiming) != hipSuccess) { ev_in_[i] = nullptr; (void)hipGetLastError(); return api_fail(GFDM_HIP_EHIP, "hipEventCreate"); }
+        if (!ev_k_[i] && hipEventCreateWithFlags(&ev_k_[i], hipEventDisableTiming) != hipSuccess) { ev_k_[i] = nullptr; (void)hipGetLastError(); return api_fail(GFDM_HIP_EHIP, "hipEventCreate"); }
     }
     return GFDM_HIP_OK;
 }
@@ -361,18 +363,20 @@ int HostPipe::ensure_copy_engines()
 // few thousand spins the stream is queried, so a faulting kernel ends the wait with its error instead of hanging the caller.
 hipError_t HostPipe::post_ticket(hipStream_t s, int slot, unsigned value)
 {
+    (void)hipGetLastError();          // (sticky: a stale error of an earlier call must not be read as this launch's)
     hipLaunchKernelGGL(k_host_ticket, dim3(1), dim3(1), 0, s, ticket_dev_ + slot * kTicketStride, value);
     return hipGetLastError();
 }
 
 hipError_t HostPipe::wait_ticket(hipStream_t s, int slot, unsigned value)
 {
-    volatile unsigned* t = ticket_ + slot * kTicketStride;
+    const unsigned* t = ticket_ + slot * kTicketStride;
+    auto reached = [&] { return (int)(__atomic_load_n(t, __ATOMIC_ACQUIRE) - value) >= 0; };      // acquire: the results were written before the ticket
     for (unsigned spins = 1;; ++spins) {
-        if ((int)(*t - value) >= 0) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }   // the results were written before the ticket
+        if (reached()) return hipSuccess;
         if ((spins & 0xFFF) == 0) {
             hipError_t e = hipStreamQuery(s);
-            if (e == hipSuccess) return ((int)(*t - value) >= 0) ? hipSuccess : hipStreamSynchronize(s);
+            if (e == hipSuccess) return reached() ? hipSuccess : hipStreamSynchronize(s);
             if (e != hipErrorNotReady) return e;
         }
         cpu_relax();
@@ -407,18 +411,25 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
         hipPointerAttribute_t a0{}, a1{};
         if (hipPointerGetAttributes(&a0, o.host) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (a0.type != hipMemoryTypeHost && a0.type != hipMemoryTypeDevice && a0.type != hipMemoryTypeManaged) continue;
-        if (hipPointerGetAttributes(&a1, static_cast<char*>(o.host) + extent[i] - 1) != hipSuccess) { (void)hipGetLastError(); continue; }
-        // device / managed memory is never bounced (a CPU copy would dereference a device address in the caller's thread): it is used in place, the
-        // caller vouching for the extent as with the *_device entry points, or refused
+        // device / managed memory is never bounced (a CPU copy would dereference a device address in the caller's thread): it is used in place when the
+        // runtime confirms that the WHOLE extent lies inside the one allocation the first byte belongs to, and refused otherwise -- an undersized buffer
+        // (last byte unmapped: the lookup fails or reports another kind) and an extent that runs on into a neighbouring allocation alike
         const bool dev_mem = a0.type == hipMemoryTypeDevice || a0.type == hipMemoryTypeManaged;
         if (a0.type == hipMemoryTypeDevice && a0.device != cur_dev) return api_fail(GFDM_HIP_EINVAL, "buffer lives in the memory of another GPU");
         if (dev_mem) {
-            if (!a0.devicePointer || a1.type != a0.type) return api_fail(GFDM_HIP_EINVAL, "device buffer: the runtime does not map the whole extent");
+            hipDeviceptr_t rbase = nullptr;
+            size_t rsize = 0;
+            const bool last_ok = hipPointerGetAttributes(&a1, static_cast<char*>(o.host) + extent[i] - 1) == hipSuccess && a1.type == a0.type;
+            const bool range_ok = last_ok && a0.devicePointer && hipMemGetAddressRange(&rbase, &rsize, a0.devicePointer) == hipSuccess &&
+                                  static_cast<char*>(a0.devicePointer) >= static_cast<char*>(rbase) &&
+                                  static_cast<char*>(a0.devicePointer) + extent[i] <= static_cast<char*>(rbase) + rsize;
+            if (!range_ok) { (void)hipGetLastError(); return api_fail(GFDM_HIP_EINVAL, "device buffer: the extent of the call does not lie inside one device allocation"); }
             direct[i] = true;
             host_mem[i] = false;
             direct_dev[i] = static_cast<char*>(a0.devicePointer);
             continue;
         }
+        if (hipPointerGetAttributes(&a1, static_cast<char*>(o.host) + extent[i] - 1) != hipSuccess) { (void)hipGetLastError(); continue; }
         if (a1.type != a0.type) continue;                             // only partly registered: bounce it
         // two registrations side by side need not be contiguous as the GPU sees them: the last byte must sit where the first one says
         if (a1.devicePointer != static_cast<char*>(a0.devicePointer) + (extent[i] - 1)) continue;
@@ -625,7 +636,7 @@ int HostPipe::run(hipStream_t stream, const HostOperand* ops, int nops, int64_t 
 
 int HostPipe::ensure_second_stream()
 {
-    if (!s_b_ && hipStreamCreateWithFlags(&s_b_, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return api_fail(GFDM_HIP_EHIP, "hipStreamCreate"); }
+    if (!s_b_ && hipStreamCreateWithFlags(&s_b_, hipStreamNonBlocking) != hipSuccess) { s_b_ = nullptr; (void)hipGetLastError(); return api_fail(GFDM_HIP_EHIP, "hipStreamCreate"); }
     return GFDM_HIP_OK;
 }
 

@@ -743,8 +743,13 @@ template <int K, int M, int EQ> constexpr int ic_mfma_waves_per_simd()
     constexpr size_t per_cu = (160 * 1024) / ((lds + 511) / 512 * 512) * (size_t)(rowgeom::wg(K) / 64);      // waves the LDS lets a CU hold
     return per_cu >= 4 * (size_t)GFDM_IC_WAVES_PER_SIMD ? GFDM_IC_WAVES_PER_SIMD : 2;
 }
+// GFDM_VALU_IC_WAVES_PER_SIMD (round 6, one experiment): the one-wavefront blocks' cancellation kernels (DPP rounds) compile to 77-79 registers = six waves per SIMD
+// where their MF / ZF siblings (53-69) get seven or eight; 8 asks hipcc for <= 64 registers.  Default 1 = no bound (see DESIGN.md section 7 for the outcome).
+#ifndef GFDM_VALU_IC_WAVES_PER_SIMD
+#define GFDM_VALU_IC_WAVES_PER_SIMD 1
+#endif
 template <int K, int M, int L, int MODE, int EQ, int ICK>
-__global__ __launch_bounds__(RowShape<K>::WG, ((MODE == RX_IC && ICK == ICK_MFMA) ? ic_mfma_waves_per_simd<K, M, EQ>() : 1)) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
+__global__ __launch_bounds__(RowShape<K>::WG, ((MODE == RX_IC && ICK == ICK_MFMA) ? ic_mfma_waves_per_simd<K, M, EQ>() : (MODE == RX_IC && K <= 64) ? GFDM_VALU_IC_WAVES_PER_SIMD : 1)) void k_row_receive(DevicePlan p, IcParams ic, EstPlan est, const cf* __restrict__ twT,
                                                                 cf* __restrict__ out, const cf* __restrict__ in,
                                                                 const cf* __restrict__ f_eq, int64_t nblocks)
 {

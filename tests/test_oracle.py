@@ -194,6 +194,29 @@ def test_tap_normalisation_and_validation():
         c_oracle.COracle(M, K, L, taps[:-1])
 
 
+def overlap_1_by_definition(d, ntaps, M, K):
+    """modulator_kernel_cc::generic_work at overlap 1, straight from its lines (lib/modulator_kernel_cc.cc:101,116-132): part_len = M * 1 / 2 (integer),
+    src_part_pos = 0, target_part_pos = k * M, so Y[k M + m] = FFT_M(d_k)[m] * taps[m] for m < M // 2, zero above, x = IFFT_N(Y) / N."""
+    D = np.fft.fft(np.asarray(d, complex).reshape(-1, K, M), axis=-1)
+    Y = np.zeros_like(D)
+    Y[..., :M // 2] = D[..., :M // 2] * np.asarray(ntaps, complex)[:M // 2]
+    return np.fft.ifft(Y.reshape(-1, K * M), axis=-1)
+
+
+@pytest.mark.parametrize("M,K", [(9, 64), (7, 12), (8, 4), (21, 37), (127, 16)])
+def test_modulator_overlap_1_follows_the_reference_lines(M, K):
+    """Overlap 1 cannot be pinned by a fixture: pygfdm's gfdm_modulate_block fails there (python/pygfdm/gfdm_modulation.py:93-98, tail_length = 0: `X[0:0] += X[-0:]`
+    does not broadcast -- tried in the build container), and the C++ carries a FIXME for it (lib/modulator_kernel_cc.cc:111-113).  What the C++ lines DO compute is
+    written out above; both oracles must equal it."""
+    rng = np.random.default_rng(M * 1000 + K)
+    taps = get_frequency_domain_filter("rrc", 0.3, M, K, 2)[:M] * np.exp(0.3j * np.arange(M))       # M complex taps
+    nt = R.normalize_taps(taps, M)
+    d = rng.standard_normal((3, M * K)) + 1j * rng.standard_normal((3, M * K))
+    want = overlap_1_by_definition(d, nt, M, K)
+    assert rel_err(R.modulate(d, nt, M, K, 1), want) < TOL_F64
+    assert rel_err(c_oracle.COracle(M, K, 1, taps).modulate(d), want) < TOL_F32
+
+
 # ---------------------------------------------------------------- composite transmitter oracles vs pygfdm frames
 
 def test_transmitter_oracles_match_pygfdm():

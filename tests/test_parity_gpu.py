@@ -258,6 +258,34 @@ def test_every_entry_point_against_oracle(M, K, L, alpha):
     assert rel_err(dem.demodulate_equalize(xe, feq), co.demodulate(xe, feq)) < TOL
 
 
+@pytest.mark.parametrize("M,K,family", [(9, 64, "generic_lds"), (7, 12, "generic_lds"), (8, 4, "generic_lds"), (21, 37, "generic_lds"), (5, 32, "generic_lds"),
+                                        (127, 16, "generic_rader")])
+def test_modulator_overlap_1_on_every_family_that_serves_it(M, K, family):
+    """Overlap 1 (part_len = M / 2, lib/modulator_kernel_cc.cc:101,116-132) outside the Rader shape: the compiled and the run-time instantiated row-lane kernels
+    start at overlap 2, so these shapes run on k_generic_modulate -- asserted, so that the family that served them is on record.  Expectation: the oracle AND the
+    lines written out (tests/test_oracle.py overlap_1_by_definition); pygfdm cannot produce this case (see there).  The receivers refuse overlap 1 as the reference does."""
+    import gfdm_amd
+    from test_oracle import overlap_1_by_definition
+    rng = np.random.default_rng(31 * M + K)
+    taps = get_frequency_domain_filter("rrc", 0.3, M, K, 2)[:M] * np.exp(0.3j * np.arange(M))
+    nt = R.normalize_taps(taps, M)
+    mod = gfdm_amd.Modulator(M, K, 1, taps)
+    assert mod.kernel_name() == family
+    assert rel_err(mod.filter_taps(), nt) < 1e-6
+    for B in (1, 6, 130):
+        d = qpsk(rng, (B, M * K)) + 0.2 * (rng.standard_normal((B, M * K)) + 1j * rng.standard_normal((B, M * K)))
+        got = mod.modulate(d)
+        check_err("mod_L1_%d_%d_B%d" % (M, K, B), rel_err(got, R.modulate(d, nt, M, K, 1)), TOL)
+        assert rel_err(got, overlap_1_by_definition(d, nt, M, K)) < TOL
+    import gfdm_python
+    assert rel_err(gfdm_python.Modulator(M, K, 1, taps).modulate(d[0]), R.modulate(d[0], nt, M, K, 1)) < TOL
+    for make in (lambda: gfdm_amd.Demodulator(M, K, 1, taps), lambda: gfdm_amd.AdvancedReceiver(M, K, 1, taps, np.arange(K), 1, R.qpsk_points()),
+                 lambda: gfdm_python.Demodulator(M, K, 1, taps)):
+        with pytest.raises(ValueError, match="overlap MUST be greater or equal 2"):          # lib/receiver_kernel_cc.cc:48-52
+            make()
+    assert gfdm_amd.capi.EINVAL_OVERLAP == -2                                               # GFDM_HIP_EINVAL_OVERLAP, include/gfdm_hip.h
+
+
 @pytest.mark.parametrize("M,K,L,alpha", SHAPES)
 @pytest.mark.parametrize("pc", [0, 1])
 def test_advanced_receiver_against_oracle(M, K, L, alpha, pc):
