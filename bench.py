@@ -113,6 +113,8 @@ def parse(argv=None):
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the N > 1 run (nccl = RCCL over xGMI; gloo lets several ranks share ONE GPU, "
                          "which is how the whole N > 1 path is exercised on a single-GPU box: every rank then uses device LOCAL_RANK %% device count)")
+    ap.add_argument("--rendezvous-timeout", type=float, default=300.0,
+                    help="N > 1: seconds the process group may take to form (store rendezvous + first barrier) before every rank gives up with rc != 0")
     ap.add_argument("--no-pin", action="store_true", help="N > 1: do not give every rank a CPU slice of its own / pin its launch thread")
     ap.add_argument("--selftest-launch", action="store_true",
                     help="no GPU, no GFDM compute: run launcher + rendezvous (gloo) + shard plan + synthetic-input checksum all-reduce "
@@ -136,7 +138,59 @@ def free_port():
         return s.getsockname()[1]
 
 
+def fail_line(rank, rc, error, **fields):
+    """A multi-GPU run that cannot start must be legible from the driver's record: rank 0 prints ONE JSON line with `error` (no `value`), every rank leaves with
+    rc != 0.  Only ever called from a process that goes on to exit -- never re-exec a process that has touched the GPU."""
+    if rank == 0:
+        print(json.dumps(dict({"error": error, "value": None}, **fields)), flush=True)
+    sys.stderr.write("bench.py rank %d: %s\n" % (rank, error))
+    sys.stderr.flush()
+    sys.exit(rc)
+
+
+def visible_devices():
+    """GPUs this process could use, WITHOUT initialising one (torch.cuda.device_count() counts through the driver's sysfs view on this image)"""
+    import torch
+    return torch.cuda.device_count()
+
+
+def form_group(a, cfg, rank, world, dev, ndev):
+    """torch.distributed process group of the run (RCCL under "nccl"; it only ever carries barriers and statistic reductions), bounded in time:
+    a rendezvous that wedges (a rank that never came up, an xGMI / RCCL bring-up that hangs) must end in rc != 0 and a readable line, not in the driver's
+    kill.  The store rendezvous and the first barrier are bounded by --rendezvous-timeout, a watchdog ends a rank that is stuck inside RCCL itself."""
+    import datetime
+    import threading
+    import torch.distributed as dist
+    limit = max(5.0, a.rendezvous_timeout)
+
+    def wedged():
+        if rank == 0:
+            print(json.dumps({"error": "process group did not form within %.0f s (%s, %d ranks): rank 0 gave up" % (limit + 60.0, a.dist_backend, world),
+                              "value": None, "n_gpus": world, "devices_visible": ndev, "metric": cfg["metric"]}), flush=True)
+        os._exit(5)
+    dog = threading.Timer(limit + 60.0, wedged)
+    dog.daemon = True
+    dog.start()
+    try:
+        if a.dist_backend == "nccl" and dev is not None:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=limit))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=limit))
+        dist.barrier()                                                # the communicator exists and every rank is here
+    except Exception as e:                                            # noqa: BLE001 -- whatever the rendezvous raises becomes the error line
+        dog.cancel()
+        fail_line(rank, 4, "process group (%s, %d ranks) failed to form: %s: %s" % (a.dist_backend, world, type(e).__name__, str(e)[:400]),
+                  n_gpus=world, devices_visible=ndev, metric=cfg["metric"])
+    dog.cancel()
+
+
 def launch_ranks(a, argv):
+    if a.dist_backend == "nccl" and not a.selftest_launch:
+        n = visible_devices()
+        if n < a.gpus:                       # before any rank exists: one GPU per rank is the contract of the RCCL run
+            fail_line(0, 3, "--gpus %d needs %d visible GPUs, this node shows %d (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES=%s / %s)"
+                      % (a.gpus, a.gpus, n, os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")),
+                      devices_visible=n, n_gpus=a.gpus, metric=CONFIGS[a.config]["metric"])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=dict(os.environ))          # (main() has set the RCCL / OpenMP defaults already)
@@ -189,7 +243,8 @@ def selftest_launch(a, cfg, rank, world, cpu_slice=None):
     import torch.distributed as dist
     from gfdm_amd import sharding, synth
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        a.dist_backend = "gloo"
+        form_group(a, cfg, rank, world, None, 0)
     plan = shard_plan(cfg, a.batch, rank, world)
     B, start, total, scaling = plan
     N = cfg["K"] * cfg["M"]
@@ -251,12 +306,13 @@ def timed_loop(step_fns, steps, warmup, world, time_kernels=True, kernel_seconds
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        for f in step_fns[(warmup + i) % nslots]:
-            f()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0           # this rank's time for its K steps; the caller takes the MAX over ranks
+    with launch_pinned():                     # N > 1: the launch loop on one CPU of this rank's slice, for the timed steps only
+        t0 = time.perf_counter()
+        for i in range(steps):
+            for f in step_fns[(warmup + i) % nslots]:
+                f()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0       # this rank's time for its K steps; the caller takes the MAX over ranks
     gc.enable()
     if dist_on:
         dist.barrier()                        # closing bracket: every rank has finished before anyone moves on
@@ -435,15 +491,58 @@ def numa_slice(pci_bus_ids, local_rank, allowed, read=None):
     return list(mine[i * per:(i + 1) * per])
 
 
+def set_affinity_all_threads(cpus):
+    """`cpus` for EVERY existing thread of this process (/proc/self/task), not only the caller: sched_setaffinity(0, ...) moves the calling thread alone,
+    and by the time the GPU's PCI location is known torch / RCCL / the HIP runtime have started threads on the old slice (round-5 advisor)."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    done = 0
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+            done += 1
+        except (AttributeError, OSError, ValueError):       # a thread that ended meanwhile
+            pass
+    return done
+
+
+_LAUNCH_PIN = {"slice": None, "cpu": None}
+
+
 def pin_launch_thread(cpu_slice):
-    """the calling (launch) thread onto the first CPU of its rank's slice; threads that exist already keep the whole slice"""
+    """Arms the launch-thread pin for the timed regions: timed_loop() narrows the CALLING thread to the first CPU of its rank's slice only between the opening and
+    the closing barrier of a timed region (launch_pinned()) and gives it the whole slice back afterwards.  A thread inherits its creator's mask, so a pin left
+    in place would put every thread started later from the launch thread -- lazily started HIP / ROCr helpers, torch intra-op threads, the library's copy-pool
+    helpers -- on that one CPU as well (round-5 advisor); inside a timed region everything has been warmed up and nothing starts threads.
+    Returns the CPU the timed regions run on (None = no pinning)."""
     if not cpu_slice:
         return None
-    try:
-        os.sched_setaffinity(0, {cpu_slice[0]})
-        return cpu_slice[0]
-    except (AttributeError, OSError):
-        return None
+    _LAUNCH_PIN["slice"], _LAUNCH_PIN["cpu"] = list(cpu_slice), cpu_slice[0]
+    return cpu_slice[0]
+
+
+class launch_pinned:
+    """with launch_pinned(): the calling thread on its rank's launch CPU (see pin_launch_thread); no-op when no pin is armed"""
+
+    def __enter__(self):
+        self.active = False
+        if _LAUNCH_PIN["cpu"] is not None:
+            try:
+                os.sched_setaffinity(0, {_LAUNCH_PIN["cpu"]})
+                self.active = True
+            except (AttributeError, OSError):
+                pass
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            try:
+                os.sched_setaffinity(0, set(_LAUNCH_PIN["slice"]))
+            except (AttributeError, OSError):
+                pass
+        return False
 
 
 def allowed_cpus():
@@ -675,8 +774,11 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP kernels have no CPU fallback")
+    ndev = visible_devices()
+    need = 1 if (world == 1 or a.dist_backend == "gloo") else local_world      # RCCL: one GPU per rank of this node
+    if ndev < need:
+        fail_line(rank, 3, ("%d ranks on this node need %d GPUs, %d visible" % (local_world, need, ndev)) if ndev else "bench.py needs an MI355X: the HIP kernels have no CPU fallback",
+                  devices_visible=ndev, n_gpus=world, ranks_on_this_node=local_world, metric=cfg["metric"])
     if a.dist_backend == "gloo":
         local = local % torch.cuda.device_count()                    # test mode: the ranks may share a GPU
     torch.cuda.set_device(local)
@@ -689,7 +791,7 @@ def main():
                 ids.append("%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id))
             near = numa_slice(ids, local, set(allowed_cpus_at_start))
             if near:
-                os.sched_setaffinity(0, near)
+                set_affinity_all_threads(near)                      # every thread that exists by now, not only this one
                 cpu_slice = near
         except Exception:                                           # (placement is an optimisation: never a reason to fail the run)
             pass
@@ -700,10 +802,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             os.environ["MASTER_PORT"] = str(free_port())
-        if a.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL; only barriers / stat reductions
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        form_group(a, cfg, rank, world, dev, ndev)
 
     import gfdm_amd
     from gfdm_amd import sharding, synth
@@ -800,7 +899,7 @@ def main():
             sb_mod.prepare(L_.gfdm_hip_modulator_work_device, [frames[s]], [(sym[s],)], [B], [stream])()
         torch.cuda.synchronize()
     piped = step_fns_on(lambda s: side[s % S].cuda_stream, lag)
-    launch_cpu = pin_launch_thread(cpu_slice)              # N > 1: the launch loop stays on one CPU of this rank's slice from here on
+    launch_cpu = pin_launch_thread(cpu_slice)              # N > 1: the timed regions' launch loops run on one CPU of this rank's slice (timed_loop)
     wall = timed_loop(piped, a.steps, a.warmup, world, time_kernels=False)[0]
     total_blocks, _, wall_max = sharding.reduce_stats(B * a.steps, zeros3(), wall, dev)
     rank_wall_ms = gather_ranks(wall * 1e3, world)         # every rank's own time for its K steps: a shortfall at N > 1 can be read off one run
@@ -1008,15 +1107,42 @@ def main():
             del fr, eq, o, fns
         result["large_batch"] = large
 
+    # the driver's record keeps the SCALAR keys of `roofline` (nested objects are dropped, other top-level keys survive by name only): the north-star kernel's
+    # readings and the sustained headline therefore go in flat, beside the nested objects kept for human readers
+    if sustained:
+        result["sustained_value"] = sustained["value"]
+        result["roofline"]["value_sustained"] = sustained["value"]
+        result["roofline"]["value_sustained_seconds"] = sustained["seconds"]
+    if want_paths:
+        nsd = result["roofline"]["north_star"]
+        flat = {"north_star_kernel": nsd["kernel"], "north_star_target_frac": 0.40, "north_star_kernel_ms": nsd["kernel_ms"], "north_star_frac": nsd["frac"],
+                "north_star_frac_pipelined": nsd["frac_pipelined"], "north_star_frac_sustained": nsd["frac_sustained"],
+                "north_star_kernel_ms_rocprofv3": nsd["kernel_ms_rocprofv3"], "north_star_frac_rocprofv3": nsd["frac_rocprofv3"]}
+        lb = result.get("large_batch", {}).get("demod_zf_ic2")
+        if lb:
+            n_ = lb["blocks_per_launch"]                   # 65 536 unless --large-batch says otherwise
+            flat.update({"north_star_frac_%d_sustained" % n_: lb["frac_of_hbm_peak"], "north_star_frac_%d_per_launch_median" % n_: lb["frac_of_hbm_peak_per_launch_median"],
+                         "north_star_frac_%d_rocprofv3" % n_: lb["frac_of_hbm_peak_rocprofv3"], "north_star_blocks_per_s_%d_sustained" % n_: lb["blocks_per_s"]})
+        result["roofline"].update(flat)
+
     if rank == 0 and world == 1:
         result["single_block_host_us"] = single_block_host(cfg, np.conj(taps))
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, taps, a.cpu_seconds)
     elif rank == 0:
         result["cpu_baseline"] = None
+    pr = torch.cuda.get_device_properties(local)
+    rank_devices = gather_ranks({"rank": rank, "device": local, "name": pr.name,
+                                 "pci": "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))}, world)
     if rank == 0:
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                                 # noqa: BLE001
+            rccl = None
         result["distributed"] = {"initialized": bool(use_dist), "backend": (a.dist_backend + (" (RCCL)" if a.dist_backend == "nccl" else "")) if use_dist else None,
-                                 "world_size": world, "collectives": "2 barriers per timed loop + 2 all-reduces per statistic (sharding.reduce_stats); no payload collective"}
+                                 "world_size": world, "rccl_version": rccl, "devices_visible": ndev, "rank_devices": rank_devices,
+                                 "collectives": "2 barriers per timed loop + 2 all-reduces per statistic (sharding.reduce_stats); no payload collective",
+                                 "scaling_curve": "none measured so far: no multi-GPU node was available to the builder or the driver in rounds 1-6" if world == 1 else "this line is one point of it"}
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()

@@ -16,7 +16,10 @@
 // its output index negated (a second scatter map).
 // Around the two row transforms of a block the subcarrier axis (K = 16) is ONE in-register 16-point codelet per column together with the
 // equaliser and the filter: load -> Rader rows -> columns -> Rader rows -> store, 8 barriers per block, two tiles of LDS (33.4 KB: four blocks per CU).
-// Vector-ALU bound (SQ counters: ~1500 vector instructions per wave, the vector pipe ~90 % busy at four waves per SIMD).
+// Vector-ALU bound.  SQ counters (profiles/r06/pmc_sq_counters_summary.csv, 4096 blocks): 1510-1590 vector instructions per wave for the plain kernels, 4200-4290
+// with two cancellation rounds; SQ_ACTIVE_INST_VALU x 4 cycles over the 1024 SIMDs = 97 k / 269 k cycles per SIMD of a 54.6 / 157 us launch, i.e. the vector pipe issues
+// during 71-74 % of the launch at the nominal 2.4 GHz (more at the clock the chip really holds under this load) with three of the four possible waves per SIMD resident on
+// average; LDS bank conflicts cost 7.4 M cycles against 5.3 M busy LDS cycles.
 //
 // Serves plain blocks: modulate, fft_[equalize_]filter_downsample, generic_work[_equalize] and the advanced receiver's cancellation rounds (incl. phase
 // compensation).  Everything else of this shape -- frames / demapper, the self-estimating receivers, the fused transmitter -- stays on the generic
@@ -72,8 +75,9 @@ constexpr int inv_mod(int a, int m)
 
 // index maps of one (P, A, B): everything a constant expression.  A row holds the A positions of one thread as bytes, padded to 16 so that a thread
 // fetches its row with one 16-byte load at kernel entry and keeps it in four registers for both transforms of the block.
+// (alignas(16): rader_prologue fetches a row through a uint4 pointer; an array of `unsigned` alone would only promise 4-byte alignment -- round-5 advisor)
 template <int P, int A, int B>
-struct RaderMaps {
+struct alignas(16) RaderMaps {
     static constexpr int n = P - 1;
     static constexpr int G = primitive_root(P);
     static_assert(A * B == n && A <= 16 && P <= 256 && dft::gcd_of(A, B) == 1, "P - 1 = A x B with coprime factors, A values per map row");
@@ -189,6 +193,7 @@ template <int K, int P, int A, int B, class Lds>
 __device__ __forceinline__ void rader_prologue(Lds& lds, const cf* __restrict__ bs, MapRow& min, MapRow& mout, MapRow& mneg)
 {
     const auto& maps = k_rader_maps<P, A, B>;
+    static_assert(alignof(RaderMaps<P, A, B>) >= 16 && sizeof(maps.in[0]) == 16 && sizeof(maps.in) % 16 == 0, "a map row is one aligned 16-byte load");
     const int t = role_id(), p2 = t % B;
     const uint4 a = *reinterpret_cast<const uint4*>(maps.in[p2]), b = *reinterpret_cast<const uint4*>(maps.out[p2]),
                 c = *reinterpret_cast<const uint4*>(maps.neg[p2]);

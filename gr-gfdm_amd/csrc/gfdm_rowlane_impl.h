@@ -744,7 +744,9 @@ template <int K, int M, int EQ> constexpr int ic_mfma_waves_per_simd()
     return per_cu >= 4 * (size_t)GFDM_IC_WAVES_PER_SIMD ? GFDM_IC_WAVES_PER_SIMD : 2;
 }
 // GFDM_VALU_IC_WAVES_PER_SIMD (round 6, one experiment): the one-wavefront blocks' cancellation kernels (DPP rounds) compile to 77-79 registers = six waves per SIMD
-// where their MF / ZF siblings (53-69) get seven or eight; 8 asks hipcc for <= 64 registers.  Default 1 = no bound (see DESIGN.md section 7 for the outcome).
+// where their MF / ZF siblings (53-69) get seven or eight.  Asking hipcc for seven (72 registers, 3-5 spilled) or eight (64, 8-12 spilled) measured SLOWER on one box,
+// three alternating collections each (profiles/r06/ic_valu_waves_ab.csv): K=64 M=9 MF + 2 IC 11.9 -> 12.9 / 13.7 us per 4096 blocks, 131 -> 137 / 144 us per 65 536;
+// ZF + 2 IC 15.0 -> 15.4 / 16.8 and 163 -> 169 / 178 us.  The kernel is bound by vector-ALU issue, not by residency.  Default 1 = no bound.
 #ifndef GFDM_VALU_IC_WAVES_PER_SIMD
 #define GFDM_VALU_IC_WAVES_PER_SIMD 1
 #endif

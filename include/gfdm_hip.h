@@ -223,7 +223,7 @@ int gfdm_hip_advanced_receiver_set_phase_compensation(gfdm_hip_advanced_receiver
 int gfdm_hip_advanced_receiver_get_phase_compensation(const gfdm_hip_advanced_receiver* a);        /* .h:64 */
 const char* gfdm_hip_advanced_receiver_kernel_name(const gfdm_hip_advanced_receiver* a);
 /* the decision rule the handle RUNS (a gfdm_hip_decision, never AUTO): QPSK / BPSK -- the sign tests, and with a real even IC kernel the
- * matrix-core rounds -- only for GNU Radio's unit constellations (every component within four f32 ulps of (+-1 +-j)/sqrt 2 resp. -1, +1 in
+ * matrix-core rounds -- only for GNU Radio's unit constellations (every component within 6 * FLT_EPSILON relative of (+-1 +-j)/sqrt 2 resp. -1, +1 -- this admits gr::digital's 0.707107 literal -- in
  * that order); any other points, also when created with an explicit QPSK / BPSK, are decided by NEAREST over the points as given */
 int gfdm_hip_advanced_receiver_decision(const gfdm_hip_advanced_receiver* a);
 /* generic_work (f_eq == NULL, .cc:93-98) / generic_work_equalize (f_eq != NULL, .cc:100-107) */

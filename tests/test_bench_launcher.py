@@ -238,3 +238,42 @@ def test_eight_rank_bench_on_one_gpu(cfg, batch):
         assert eight["scaling"] == "strong" and eight["config"]["blocks_per_step_all_gpus"] == batch and eight["config"]["batch_per_gpu"] == batch // 8
         for a, b in zip(one["output_checksum"], eight["output_checksum"]):
             assert abs(a - b) <= 1e-9 * max(1.0, abs(a))
+
+
+def _raw_bench(args, extra_env=None, timeout=300):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True, text=True, timeout=timeout)
+    return p.returncode, [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")], p.stderr
+
+
+@pytest.mark.timeout(300)
+def test_more_ranks_than_visible_gpus_is_one_legible_error_line_and_a_nonzero_exit():
+    """The first 8-GPU run cannot be rehearsed: if the node shows fewer GPUs than ranks under RCCL, rank 0 prints ONE JSON line with `error` and
+    `devices_visible`, and the run ends with rc != 0 -- before any rank exists when bench.py starts the ranks itself, in every rank under somebody's torchrun."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box really has 8 GPUs")
+    n = torch.cuda.device_count()
+    rc, lines, err = _raw_bench(["--gpus", "8", "--steps", "2", "--warmup", "1"])
+    assert rc == 3 and len(lines) == 1, err[-1500:]
+    assert lines[0]["devices_visible"] == n and lines[0]["n_gpus"] == 8 and "8" in lines[0]["error"] and lines[0]["value"] is None
+    # the driver's way: ranks started by torchrun; every rank leaves with rc != 0, only rank 0 prints
+    for rank in (0, 1):
+        rc, lines, err = _raw_bench(["--gpus", "8", "--steps", "2", "--warmup", "1"],
+                                    {"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "8", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+        assert rc == 3 and len(lines) == (1 if rank == 0 else 0), err[-1500:]
+        assert "rank %d" % rank in err
+
+
+@pytest.mark.timeout(300)
+def test_a_rendezvous_that_never_completes_ends_in_an_error_line_not_in_a_hang():
+    """rank 0 of a two-rank group whose rank 1 never starts: the store rendezvous gives up after --rendezvous-timeout, rank 0 prints the error line, rc = 4"""
+    import time
+    t0 = time.time()
+    rc, lines, err = _raw_bench(["--selftest-launch", "--gpus", "2", "--rendezvous-timeout", "6"],
+                                {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2", "LOCAL_WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    assert rc == 4 and len(lines) == 1 and "failed to form" in lines[0]["error"] and lines[0]["n_gpus"] == 2, (rc, lines, err[-1500:])
+    assert time.time() - t0 < 120

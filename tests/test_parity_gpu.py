@@ -632,7 +632,7 @@ def test_ic_rounds_on_the_matrix_cores_match_the_vector_alu(M, K, L, alpha):
 
 def test_decision_rule_a_handle_runs_is_reported():
     """gfdm_hip_advanced_receiver_decision: the sign tests (and with them the matrix-core cancellation rounds) only for GNU Radio's unit QPSK / BPSK
-    points -- every component within four float32 ulps --; scaled, rotated or perturbed points are decided by the nearest-point rule over the points
+    points -- every component within 6 * FLT_EPSILON relative, which admits GNU Radio's 0.707107 literal --; scaled, rotated or perturbed points are decided by the nearest-point rule over the points
     as given, also when 'qpsk' / 'bpsk' was asked for, and the handle says so."""
     import gfdm_amd
     M, K, L = 9, 64, 2
@@ -641,6 +641,15 @@ def test_decision_rule_a_handle_runs_is_reported():
     mk = lambda pts, dec: gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, pts, decision=dec).decision_rule()
     assert mk(q, "auto") == "qpsk" and mk(q, "qpsk") == "qpsk" and mk(q, "nearest") == "nearest"
     assert mk(q.astype(np.complex64) * np.complex64(1 + 1.2e-7), "auto") == "qpsk"           # one or two ulps off: still the unit constellation
+    # gr::digital::constellation_qpsk is built from the LITERAL SQRT_TWO = 0.707107 (3.8 float ulps from 1 / sqrt 2): GNU Radio's own object must get the
+    # sign tests -- and the handle's results with it stay within the tolerance of the oracle run on those very points
+    gr_q = (np.array([-1 - 1j, 1 - 1j, -1 + 1j, 1 + 1j]) * np.float32(0.707107)).astype(np.complex64)
+    assert mk(gr_q, "auto") == "qpsk" and mk(gr_q, "qpsk") == "qpsk"
+    rng = np.random.default_rng(5)
+    nt = R.normalize_taps(taps, M)
+    x = R.modulate(qpsk(rng, (6, M * K)), nt, M, K, L)
+    adv = gfdm_amd.AdvancedReceiver(M, K, L, taps, np.arange(K), 2, gr_q)
+    assert rel_err(adv.demodulate(x), R.advanced_receive(x, nt, M, K, L, np.arange(K), gr_q.astype(complex), 2, kind="qpsk")) < TOL
     assert mk(q * (1 + 1e-6), "auto") == "nearest" and mk(q * (1 + 1e-6), "qpsk") == "nearest"
     assert mk(2 * q, "qpsk") == "nearest" and mk(q * np.exp(0.3j), "qpsk") == "nearest"
     assert mk(np.array([-1, 1]), "auto") == "bpsk" and mk(np.array([-2, 2]), "bpsk") == "nearest"
