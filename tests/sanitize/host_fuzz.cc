@@ -211,7 +211,7 @@ struct Handles {
     gfdm_hip_transmitter* tx = nullptr;
     gfdm_hip_channel_estimator* est = nullptr;
     int device = 0, cp = 0, A = 0, ic_iter = 2, F = 0, nports = 0;
-    bool frames = false;
+    bool frames = false, estimated = false;
     ~Handles()
     {
         if (mod) gfdm_hip_modulator_destroy(mod);
@@ -272,6 +272,12 @@ std::unique_ptr<Handles> make_handles(std::mt19937& rng, bool allow_failure)
         rc = product([&] { return gfdm_hip_channel_estimator_create(&h->est, s.M, s.K, A > s.K - 1 ? ((s.K - 1) & ~1) : A, 1, 1, pre.data(), 2 * s.K, h->device); });
         if (rc != GFDM_HIP_OK) { CHECK(allow_failure, "channel_estimator_create %d: %s", rc, gfdm_hip_last_error()); return nullptr; }
     }
+    if (h->est && rng() % 2) {                             // receivers that estimate the channel themselves (run-time instantiated shapes: their preamble-equalised
+        rc = product([&] { return gfdm_hip_receiver_set_channel_estimator(h->rx, h->est); });            // kernels may come from the background pool)
+        if (rc == GFDM_HIP_OK) rc = product([&] { return gfdm_hip_advanced_receiver_set_channel_estimator(h->adv, h->est); });
+        if (rc != GFDM_HIP_OK) { CHECK(allow_failure, "set_channel_estimator %d", rc); return nullptr; }
+        h->estimated = true;
+    }
     return h;
 }
 
@@ -285,19 +291,21 @@ bool one_call(Handles& h, std::mt19937& rng, bool allow_failure)
     random_pipeline(rng, (int64_t)N * 8);
     CHECK(hipSetDevice(h.device) == hipSuccess, "hipSetDevice");      // device operands must live on the handle's GPU (another GPU's memory is refused: tested below)
     const unsigned seed = (unsigned)rng();
-    int which = (int)(rng() % 10);
+    int which = (int)(rng() % 11);
+    if (which == 10 && !h.estimated) which = 4;
     if (which == 7 && !h.tx) which = 0;
     if (which == 8 && !h.est) which = 1;
     if ((which == 5 || which == 6) && !h.frames) which = 2 + (int)(rng() % 2);
     const bool with_eq = rng() % 2;
     Buf out, in0, in1;
     int rc = GFDM_HIP_OK;
-    auto check_rx = [&](int mode, int rounds, int64_t in_stride, int in_off, int nout, const Buf* e) {
+    auto check_rx = [&](int mode, int rounds, int64_t in_stride, int in_off, int nout, const Buf* e, int64_t e_stride = -1, int e_mod = 0) {
+        if (e_stride < 0) { e_stride = N; e_mod = N; }          // the equaliser vector: N bins per block; a preamble: 2 K samples at its stride
         float tag = 0.f;
         for (int64_t b = 0; b < nb; ++b)
             for (int i = 0; i < nout; ++i) {
                 const c2 sv = at(in0, b * in_stride + in_off + (i % N));
-                const c2 ev = e ? at(*e, b * N + (i % N)) : c2{ 0.f, 0.f };
+                const c2 ev = e ? at(*e, b * e_stride + (i % e_mod)) : c2{ 0.f, 0.f };
                 const c2 got = at(out, b * nout + i);
                 if (b == 0 && i == 0) {
                     tag = -1.f;
@@ -396,6 +404,20 @@ bool one_call(Handles& h, std::mt19937& rng, bool allow_failure)
                 if (b == 0 && i == 0) tag = at(out, 0).x - loopback::est_value(sv, 0, 3, 0.f).x;
                 CHECK(same(at(out, b * N + i), loopback::est_value(sv, 0, 3, tag)), "estimate_frame block %ld element %d", (long)b, i);
             }
+        break;
+    }
+    case 10: {                                             // self-estimating receivers: the received preambles as third operand, read at a stride
+        const int pre_stride = (rng() % 2) ? 0 : 2 * s.K + 2 * (int)(rng() % 5), ps = pre_stride ? pre_stride : 2 * s.K;
+        const int64_t in_stride = h.frames ? h.F : N;
+        const int nout = h.frames ? h.A * s.M : N;
+        in0.alloc(pick_kind(rng), (size_t)nb * in_stride * 8, rng); fill(in0, seed, nb * in_stride);
+        in1.alloc(pick_kind(rng), ((size_t)(nb - 1) * ps + 2 * s.K) * 8, rng); fill(in1, seed ^ 0x4242, (nb - 1) * ps + 2 * s.K);
+        out.alloc(pick_kind(rng), (size_t)nb * nout * 8, rng); poison(out, nb * nout);
+        const bool adv = rng() % 2;
+        if (adv) rc = product([&] { return gfdm_hip_advanced_receiver_work_estimated_host(h.adv, out.p, in0.p, in1.p, pre_stride, 0, nb); });
+        else rc = product([&] { return gfdm_hip_receiver_demodulate_estimated_host(h.rx, out.p, in0.p, in1.p, pre_stride, 0, nb); });
+        if (rc != GFDM_HIP_OK) break;
+        check_rx(adv ? 2 : 1, adv ? h.ic_iter : 0, in_stride, h.frames ? h.cp : 0, nout, &in1, ps, 2 * s.K);
         break;
     }
     default: {                                             // the stand-alone stages (generic kernels): cancel_sc_interference with three operands
