@@ -66,6 +66,7 @@ out += ["", "## Files of round 6", "",
         "| `r06/pmc_sq_counters_summary.csv` | SQ counters of the K=64 M=9 MF / MF + 2 IC / ZF + 2 IC kernels at 65 536 and 4096 blocks and of the Rader kernels (the table above) |",
         "| `r06/kernel_alone.csv`, `r06/pmc_hbm_traffic_summary.csv`, `r06/build_id.txt` | the tables above; `bench.py` reads them for `kernel_ms_rocprofv3` / `traffic` when the build id matches |",
         "| `r06/bench_default.json`, `bench_driver_line.json`, `bench_cfg3.json`, `bench_cfg4.json`, `bench_cfg5.json` | `bench.py` lines of the final build; `roofline` now carries the north-star kernel's readings as scalar keys (`north_star_frac*`) and `value_sustained` |",
+        "| `r06/sticky_error_before_after.txt` | the sanitizer harness's first finding on the real runtime: after an application's failed `hipMalloc` the pre-fix library fails its next launch with `kernel launch: out of memory`, the fixed one does not |",
         "| `r06/pytest_gpu_suite.txt`, `r06/fuzz_final_build.txt` | the `-m gpu` suite and the two GPU fuzzers on the final tree |", ""]
 open(os.path.join(ROOT, "profiles", "README.md"), "w").write("\n".join(out))
 print("\n".join(out[:14]))

@@ -412,3 +412,38 @@ def test_automatic_chunk_plan_of_small_and_mid_size_calls(pipeline):
         assert st["chunks"] == chunks and st["chunk_blocks"] == -(-nb // chunks), (nb, st)
         assert (st["copy_threads"] >= 1) == (st["chunk_blocks"] * 2 * N * 8 >= (1 << 20)), (nb, st)      # the pool takes copy jobs of 1 MiB and more
         assert np.array_equal(out, want[:nb]), nb
+
+
+def test_a_stale_hip_error_of_the_application_does_not_fail_the_next_call():
+    """hipGetLastError() is sticky: it keeps the error of any earlier failed runtime call of the thread until somebody reads it, and the launchers check their
+    launches with it.  An application call that failed (here: an allocation nobody could satisfy) must not make the next GFDM call fail -- found by the injected
+    failures of tests/sanitize, fixed at call entry (DeviceGuard) and in front of the completion-ticket launch; this is the same on the real runtime."""
+    import ctypes
+    import torch
+    import gfdm_amd
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    M, K, L = 9, 64, 2
+    taps = get_frequency_domain_filter("rrc", 0.2, M, K, L)
+    mod, dem = gfdm_amd.Modulator(M, K, L, taps), gfdm_amd.Demodulator(M, K, L, taps)
+    rng = np.random.default_rng(3)
+    d = qpsk(rng, (5, M * K))
+    want = mod.modulate(d)
+    want_rx = dem.demodulate(want)
+    for entry in ("host", "device"):
+        p = ctypes.c_void_p()
+        if entry == "host":
+            assert hip.hipMalloc(ctypes.byref(p), 1 << 60) != 0      # fails, and leaves its error behind in this thread
+            got = mod.modulate(d)                                     # numpy in: the *_host entry point (launch + completion ticket)
+            got_rx = dem.demodulate(got)
+        else:
+            dt = torch.from_numpy(d).cuda()                           # (torch first: its own launch checks trip over a stale error just the same)
+            o1, o2 = torch.empty_like(dt), torch.empty_like(dt)
+            torch.cuda.synchronize()
+            assert hip.hipMalloc(ctypes.byref(p), 1 << 60) != 0      # no torch call between the failure and ours
+            mod.modulate(dt, out=o1)                                  # tensors in: the *_device entry point
+            assert hip.hipMalloc(ctypes.byref(p), 1 << 60) != 0
+            dem.demodulate(o1, out=o2)
+            torch.cuda.synchronize()
+            got, got_rx = o1.cpu().numpy(), o2.cpu().numpy()
+        assert np.array_equal(got, want) and np.array_equal(got_rx, want_rx)
