@@ -1076,7 +1076,8 @@ def main():
             # three readings of the same kernel in one run: (1) a burst of 10 launches right after the set-up, one event pair around it -- what
             # round 4 reported as kernel_ms; it depends on the clock state the idle gap left behind (0.54 of peak on one box, 0.73 on the next);
             # (2) back to back for >= 1 s after a warm-up run: the steady state; (3) the median of per-launch event pairs over an equally long run.
-            # (2) and (3) agree within 2 %, and with rocprofv3's kernel duration within 3 % (profiles/r05/sustained_vs_burst.txt).
+            # (2) and (3) agree within 2 % (profiles/r05/sustained_vs_burst.txt); rocprofv3's kernel duration -- one kernel on the GPU at a time, no overlap of one launch's
+            # tail with the next one's head -- reads up to 10 % longer.
             torch.cuda.synchronize()
             eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             eb0.record()
