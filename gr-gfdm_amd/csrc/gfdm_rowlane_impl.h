@@ -469,14 +469,19 @@ __device__ __forceinline__ void wave_fft_first_pass(cf* tile, int lane, const Ff
     block_sync<64>();
 }
 
-// lane i <- lane (i -+ 1) mod 64: DPP wave rotates (GFX9 dpp_ctrl 0x13C = wave_ror:1, 0x134 = wave_rol:1)
+// lane i <- lane (i -+ 1) mod 64: DPP wave rotates (GFX9 dpp_ctrl 0x13C = wave_ror:1, 0x134 = wave_rol:1).
+// Spelled as update_dpp with a zero `old` and bound_ctrl: a rotate has a source lane for every lane, so neither changes the value -- but in this form hipcc's DPP
+// combine folds a rotate that has ONE use into that use (v_add_f32_dpp / v_fmac_f32_dpp) instead of issuing a v_mov_b32_dpp of its own, which the mov_dpp spelling
+// never got: one vector instruction less per neighbour component in every cancellation round of the vector-ALU-bound K = 64 kernels (18 of a round's 171; the filter's
+// rotates feed products with taps held in SGPRs, which VOP2-with-DPP cannot encode, and stay).  Same-box A/B, three alternating collections
+// (profiles/r06/ic_dpp_fold_ab.csv): MF + 2 IC 134.4 -> 130.9 us per 65 536 blocks, ZF + 2 IC 14.39 -> 14.02 us per 4096; the other two points within the noise.
 __device__ __forceinline__ float dpp_wave_ror1(float x)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x13C, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float dpp_wave_rol1(float x)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x134, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x134, 0xF, 0xF, true));
 }
 
 // c + t x for a filter tap t: prototype filters such as RRC / RC have REAL frequency-domain taps (DevicePlan::taps_real, decided once per

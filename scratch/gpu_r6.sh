@@ -34,6 +34,23 @@ icw)
   done
   unset GFDM_HIP_LIB
   cut -d, -f1,7- $O/ic_valu_waves_ab.csv ;;
+dppfold)   # the DPP rotates folded into their one use (v_add_f32_dpp): scratch/ab/dppfold against the library of the tree, parity first, then three alternating collections
+  export GFDM_HIP_LIB=$R/scratch/ab/dppfold/libgfdm_hip.so
+  (cd $R && timeout 1200 python -m pytest tests/test_parity_gpu.py tests/test_stated_batch_gpu.py -x -q -k "advanced or ic or stated or golden" 2>&1 | tail -3)
+  unset GFDM_HIP_LIB
+  echo "label,kernel,workgroups,workgroup_size,queue,launches,mean_us,median_us,min_us,max_us" > $O/ic_dpp_fold_ab.csv
+  for rep in 1 2 3; do
+    for v in tree dppfold; do
+      lib=$R/gr-gfdm_amd/lib/libgfdm_hip.so; [ $v != tree ] && lib=$R/scratch/ab/$v/libgfdm_hip.so
+      export GFDM_HIP_LIB=$lib
+      for p in demod_mf_ic2 demod_zf_ic2; do
+        trace $O/ic_dpp_fold_ab.csv ${v}_${p}_4096_r$rep 200 $p 4096 400 36
+        trace $O/ic_dpp_fold_ab.csv ${v}_${p}_65536_r$rep 30 $p 65536 60 3
+      done
+    done
+  done
+  unset GFDM_HIP_LIB
+  cut -d, -f1,7- $O/ic_dpp_fold_ab.csv | sed 's/"//g' ;;
 sq)
   rm -rf $O/sq; mkdir -p $O/sq
   id=$(python3 -c "import sys; sys.path.insert(0, '$R/gr-gfdm_amd/python'); import gfdm_amd; print(gfdm_amd.build_id())")
