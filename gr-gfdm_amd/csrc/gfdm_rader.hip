@@ -16,10 +16,10 @@
 // its output index negated (a second scatter map).
 // Around the two row transforms of a block the subcarrier axis (K = 16) is ONE in-register 16-point codelet per column together with the
 // equaliser and the filter: load -> Rader rows -> columns -> Rader rows -> store, 8 barriers per block, two tiles of LDS (33.4 KB: four blocks per CU).
-// Vector-ALU bound.  SQ counters (profiles/r06/pmc_sq_counters_summary.csv, 4096 blocks): 1510-1590 vector instructions per wave for the plain kernels, 4200-4290
-// with two cancellation rounds; SQ_ACTIVE_INST_VALU x 4 cycles over the 1024 SIMDs = 97 k / 269 k cycles per SIMD of a 54.6 / 157 us launch, i.e. the vector pipe issues
-// during 71-74 % of the launch at the nominal 2.4 GHz (more at the clock the chip really holds under this load) with three of the four possible waves per SIMD resident on
-// average; LDS bank conflicts cost 7.4 M cycles against 5.3 M busy LDS cycles.
+// Limited by its vector work.  SQ counters (profiles/r06/pmc_sq_counters_summary.csv, 4096 blocks): 1510-1590 vector instructions per wave for the plain kernels, 4200-4290
+// with two cancellation rounds, three of the four possible waves per SIMD resident on average; a wave issues one vector instruction per four clocks (SQ_ACTIVE_INST_VALU x 4 =
+// 97 k / 269 k clocks of wave issue per SIMD in a 54 / 157 us launch of 131 k / 377 k clocks), the SIMD retires a plain one in two (MI355X_MICROARCH.md) -- the pipe is a third
+// to a half busy, the three resident waves' dependent chains and their 8 barriers per block leave it idle the rest; LDS bank conflicts add a third to the busy LDS cycles.
 //
 // Serves plain blocks: modulate, fft_[equalize_]filter_downsample, generic_work[_equalize] and the advanced receiver's cancellation rounds (incl. phase
 // compensation).  Everything else of this shape -- frames / demapper, the self-estimating receivers, the fused transmitter -- stays on the generic

@@ -472,7 +472,7 @@ __device__ __forceinline__ void wave_fft_first_pass(cf* tile, int lane, const Ff
 // lane i <- lane (i -+ 1) mod 64: DPP wave rotates (GFX9 dpp_ctrl 0x13C = wave_ror:1, 0x134 = wave_rol:1).
 // Spelled as update_dpp with a zero `old` and bound_ctrl: a rotate has a source lane for every lane, so neither changes the value -- but in this form hipcc's DPP
 // combine folds a rotate that has ONE use into that use (v_add_f32_dpp / v_fmac_f32_dpp) instead of issuing a v_mov_b32_dpp of its own, which the mov_dpp spelling
-// never got: one vector instruction less per neighbour component in every cancellation round of the vector-ALU-bound K = 64 kernels (18 of a round's 171; the filter's
+// never got: one vector instruction less per neighbour component in every cancellation round of the K = 64 kernels (18 of a round's 171; the filter's
 // rotates feed products with taps held in SGPRs, which VOP2-with-DPP cannot encode, and stay).  Same-box A/B, three alternating collections
 // (profiles/r06/ic_dpp_fold_ab.csv): MF + 2 IC 134.4 -> 130.9 us per 65 536 blocks, ZF + 2 IC 14.39 -> 14.02 us per 4096; the other two points within the noise.
 __device__ __forceinline__ float dpp_wave_ror1(float x)
@@ -751,7 +751,7 @@ template <int K, int M, int EQ> constexpr int ic_mfma_waves_per_simd()
 // GFDM_VALU_IC_WAVES_PER_SIMD (round 6, one experiment): the one-wavefront blocks' cancellation kernels (DPP rounds) compile to 77-79 registers = six waves per SIMD
 // where their MF / ZF siblings (53-69) get seven or eight.  Asking hipcc for seven (72 registers, 3-5 spilled) or eight (64, 8-12 spilled) measured SLOWER on one box,
 // three alternating collections each (profiles/r06/ic_valu_waves_ab.csv): K=64 M=9 MF + 2 IC 11.9 -> 12.9 / 13.7 us per 4096 blocks, 131 -> 137 / 144 us per 65 536;
-// ZF + 2 IC 15.0 -> 15.4 / 16.8 and 163 -> 169 / 178 us.  The kernel is bound by vector-ALU issue, not by residency.  Default 1 = no bound.
+// ZF + 2 IC 15.0 -> 15.4 / 16.8 and 163 -> 169 / 178 us.  Residency bought with spills does not pay; fewer instructions do.  Default 1 = no bound.
 #ifndef GFDM_VALU_IC_WAVES_PER_SIMD
 #define GFDM_VALU_IC_WAVES_PER_SIMD 1
 #endif

@@ -44,10 +44,11 @@ for r in csv.DictReader(open(os.path.join(P, "kernel_alone.csv"))):
 sq = {}
 for r in csv.DictReader(open(os.path.join(P, "pmc_sq_counters_summary.csv"))):
     sq.setdefault((r["run"], r["kernel"]), {})[r["counter"]] = float(r["mean"])
-out += ["", "## Vector-ALU issue time (`r06/pmc_sq_counters_summary.csv`, `scratch/gpu_r6.sh sq`; SQ_* cycle counters tick once per four clocks)", "",
-        "VALU busy = SQ_ACTIVE_INST_VALU x 4 clocks / 1024 SIMDs / (rocprofv3 duration x 2.4 GHz): the share of the launch during which a SIMD issues vector instructions, at the nominal clock",
-        "(the chip holds less under these loads, so the true share is higher).  Resident waves = SQ_WAVE_CYCLES x 4 / (GRBM_GUI_ACTIVE / 8) / 1024.", "",
-        "| run | kernel | VALU instructions / wave | VALU clocks / SIMD | launch us | VALU busy at 2.4 GHz | resident waves / SIMD | LDS bank-conflict cycles / busy LDS cycles |", "|---|---|---|---|---|---|---|---|"]
+out += ["", "## Vector work (`r06/pmc_sq_counters_summary.csv`, `scratch/gpu_r6.sh sq`; SQ_* cycle counters tick once per four clocks)", "",
+        "Wave issue = SQ_ACTIVE_INST_VALU x 4 clocks / 1024 SIMDs / (rocprofv3 duration x 2.4 GHz): the clocks the waves of a SIMD spend issuing vector instructions (one per 4 clocks and wave), over the launch;",
+        "two waves can issue side by side, so this is NOT the pipe's utilisation.  Pipe (lower bound) = vector instructions x 2 clocks (what the SIMD needs for a plain wave64 f32 instruction,",
+        "`MI355X_MICROARCH.md`; packed f32, DPP and lane swaps cost 4.3-8.2, `scratch/probe/pk_rate.hip`) over the same.  Resident waves = SQ_WAVE_CYCLES x 4 / (GRBM_GUI_ACTIVE / 8) / 1024.", "",
+        "| run | kernel | vector instructions / wave | launch us | wave issue / launch | pipe, lower bound | resident waves / SIMD | LDS bank-conflict cycles / busy LDS cycles |", "|---|---|---|---|---|---|---|---|"]
 for (run, kern), v in sorted(sq.items()):
     parts = run.split("_")
     B, K, M, L = int(parts[-1]), int(parts[-4]), int(parts[-3]), int(parts[-2])
@@ -56,9 +57,10 @@ for (run, kern), v in sorted(sq.items()):
     if us is None or "SQ_ACTIVE_INST_VALU" not in v:
         continue
     clk = v["SQ_ACTIVE_INST_VALU"] * 4 / 1024
+    pipe = v["SQ_INSTS_VALU"] * 2 / 1024
     res = v["SQ_WAVE_CYCLES"] * 4 / (v["GRBM_GUI_ACTIVE"] / 8) / 1024 if v.get("GRBM_GUI_ACTIVE") else float("nan")
-    out.append("| %s | `%s` | %.0f | %.0f | %.2f | **%.0f %%** | %.1f | %.2f |" % (run, kern, v["SQ_INSTS_VALU"] / v["SQ_WAVES"], clk, us, 100 * clk / (us * 2400), res,
-                                                                          v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_ACTIVE_INST_LDS"] * 4, 1)))
+    out.append("| %s | `%s` | %.0f | %.2f | %.0f %% | **%.0f %%** | %.1f | %.2f |" % (run, kern, v["SQ_INSTS_VALU"] / v["SQ_WAVES"], us, 100 * clk / (us * 2400), 100 * pipe / (us * 2400), res,
+                                                                           v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_ACTIVE_INST_LDS"] * 4, 1)))
 out += ["", "## Files of round 6", "",
         "| file | what |", "|---|---|",
         "| `r06/sanitizers_host_side.txt` | `make -C tests/sanitize run`: the host-side code (C-ABI, host-buffer path, run-time instantiation, C++ classes, sharded batch) under ThreadSanitizer and AddressSanitizer + UBSan against the loop-back HIP layer, 20 s each, clean; what the first runs found is in `tests/test_sanitizers.py` |",
