@@ -2,6 +2,7 @@
 # Round-6 GPU runner:   gpurun -- bash scratch/gpu_r6.sh <task> [tag]
 #   icw        VERDICT r05 item 4, the ONE experiment: K=64 M=9 MF / ZF + 2 IC kernels (DPP rounds) built with a register bound (7 / 8 waves per SIMD) against the
 #              tree's unbounded build (77-79 registers = 6 waves), rocprofv3 kernel durations, three alternating collections each
+#   pkrate     issue costs of the vector instruction classes (round-2 probe)
 #   sq         SQ counters (three passes) of the K=64 M=9 MF + 2 IC kernel and its MF sibling at 65 536 / 4096 blocks, and of the Rader kernels of M=127 K=16
 #   tests / bench / alone / pmc: as scratch/gpu_r5.sh (delegated)
 R=$GRAFT_REPO_ROOT; T=${2:-r6}; O=$R/gpurun_out/$T; mkdir -p $O
@@ -51,6 +52,8 @@ dppfold)   # the DPP rotates folded into their one use (v_add_f32_dpp): scratch/
   done
   unset GFDM_HIP_LIB
   cut -d, -f1,7- $O/ic_dpp_fold_ab.csv | sed 's/"//g' ;;
+pkrate)    # issue costs of plain / packed f32, DPP moves and lane swaps at 4 and 16 waves per CU (scratch/probe/pk_rate.hip, the round-2 probe): what the vector-work reading of DESIGN.md section 7 rests on
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $R/scratch/probe/pk_rate.hip -o /tmp/pk_rate 2>/dev/null && timeout 120 /tmp/pk_rate > $O/valu_issue_costs.txt 2>&1; cat $O/valu_issue_costs.txt ;;
 sq)
   rm -rf $O/sq; mkdir -p $O/sq
   id=$(python3 -c "import sys; sys.path.insert(0, '$R/gr-gfdm_amd/python'); import gfdm_amd; print(gfdm_amd.build_id())")
