@@ -52,6 +52,23 @@ dppfold)   # the DPP rotates folded into their one use (v_add_f32_dpp): scratch/
   done
   unset GFDM_HIP_LIB
   cut -d, -f1,7- $O/ic_dpp_fold_ab.csv | sed 's/"//g' ;;
+icfast)    # clean residency A/B (no spills): the cancellation kernels compiled WITHOUT their cold paths (phase compensation, nearest-point decisions) = 62 / 70 registers = eight /
+           # seven waves per SIMD instead of six (scratch/ab/icfast, a timing-only hack of the header), against the library of the tree; also cfg4's shape
+  echo "label,kernel,workgroups,workgroup_size,queue,launches,mean_us,median_us,min_us,max_us" > $O/ic_hot_path_only_ab.csv
+  for rep in 1 2 3; do
+    for v in tree icfast; do
+      lib=$R/gr-gfdm_amd/lib/libgfdm_hip.so; [ $v != tree ] && lib=$R/scratch/ab/$v/libgfdm_hip.so
+      export GFDM_HIP_LIB=$lib
+      for p in demod_mf_ic2 demod_zf_ic2; do
+        trace $O/ic_hot_path_only_ab.csv ${v}_${p}_4096_r$rep 200 $p 4096 400 36
+        trace $O/ic_hot_path_only_ab.csv ${v}_${p}_65536_r$rep 30 $p 65536 60 3
+      done
+      trace $O/ic_hot_path_only_ab.csv ${v}_128_15_4_demod_mf_ic2_8192_r$rep 20 demod_mf_ic2 8192 40 2 128 15 4
+      trace $O/ic_hot_path_only_ab.csv ${v}_128_15_4_demod_mf_ic2_65536_r$rep 20 demod_mf_ic2 65536 40 2 128 15 4
+    done
+  done
+  unset GFDM_HIP_LIB
+  cut -d, -f1,7- $O/ic_hot_path_only_ab.csv | sed 's/"//g' ;;
 pkrate)    # issue costs of plain / packed f32, DPP moves and lane swaps at 4 and 16 waves per CU (scratch/probe/pk_rate.hip, the round-2 probe): what the vector-work reading of DESIGN.md section 7 rests on
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $R/scratch/probe/pk_rate.hip -o /tmp/pk_rate 2>/dev/null && timeout 120 /tmp/pk_rate > $O/valu_issue_costs.txt 2>&1; cat $O/valu_issue_costs.txt ;;
 sq)

@@ -67,6 +67,7 @@ out += ["", "## Files of round 6", "",
         "| `r06/ic_valu_waves_ab.csv` | the ONE experiment on the K=64 M=9 cancellation kernels: a register bound for seven / eight waves per SIMD against the unbounded build (six), three alternating collections on one box -- slower (DESIGN.md section 7) |",
         "| `r06/valu_issue_costs.txt` | `scratch/probe/pk_rate.hip` on the box of the final collection: clocks per wave-instruction of plain / packed f32, DPP moves and lane swaps at 4 and 16 waves per CU (2.4-2.7 / 4.8 / 4.3 / 8.3) -- what the pipe estimates of DESIGN.md section 7 are priced with |",
         "| `r06/fuzz_host_path_soak.txt` | 15 minutes of `scratch/fuzz_host_path.py` on the GPU (187 600 random host calls, every result equal to the device path) |",
+        "| `r06/ic_dpp_fold_ab.csv`, `r06/ic_hot_path_only_ab.csv` | same-box A/Bs behind DESIGN.md section 7: the DPP rotates folded into their adds (kept, -2.6 %), and the IC kernels without their cold paths = eight / seven waves per SIMD without spills (timing only: <= 1.5 % at 65 536 blocks, not kept) |",
         "| `r06/pmc_sq_counters_summary.csv` | SQ counters of the K=64 M=9 MF / MF + 2 IC / ZF + 2 IC kernels at 65 536 and 4096 blocks and of the Rader kernels (the table above) |",
         "| `r06/kernel_alone.csv`, `r06/pmc_hbm_traffic_summary.csv`, `r06/build_id.txt` | the tables above; `bench.py` reads them for `kernel_ms_rocprofv3` / `traffic` when the build id matches |",
         "| `r06/bench_default.json`, `bench_driver_line.json`, `bench_cfg3.json`, `bench_cfg4.json`, `bench_cfg5.json` | `bench.py` lines of the final build; `roofline` now carries the north-star kernel's readings as scalar keys (`north_star_frac*`) and `value_sustained` |",
